@@ -1,0 +1,179 @@
+/*
+ * msgl_hip.h — C ABI of libmsgl_hip.so: the MI355X (gfx950) kernels behind
+ * mini-sglang's attention-backend interface and its RMSNorm / SiluAndMul /
+ * RotaryEmbedding layers.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch-allocated
+ *     tensors in the host mirror); the library never allocates or frees device
+ *     memory and keeps no state besides a thread-local error string;
+ *   - activations / caches are bf16 (2-byte elements), index tensors int32,
+ *     strides are in ELEMENTS of the tensor they describe;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     work is only enqueued, never synchronised, so every call is legal under
+ *     hipGraph stream capture;
+ *   - return value 0 = success; negative = error (MSGL_E_*), with a message
+ *     retrievable through msgl_last_error().  The Python mirror raises
+ *     RuntimeError(msgl_last_error()) on any non-zero return, which matches the
+ *     reference's behaviour of letting a kernel error kill the scheduler rank
+ *     (reference: mini_sglang/managers/scheduler.py:559-567).
+ *
+ * The reference is pure Python; the interface each entry point replaces is the
+ * Python call named in its comment (paths relative to the reference root).
+ */
+#ifndef MSGL_HIP_H
+#define MSGL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSGL_OK 0
+#define MSGL_E_INVALID (-1)   /* bad argument (shape, alignment, unsupported size) */
+#define MSGL_E_LAUNCH (-2)    /* hipLaunchKernel reported an error */
+#define MSGL_E_WORKSPACE (-3) /* workspace too small */
+
+/* ABI version of this header; bumped when a signature changes. */
+int msgl_abi_version(void);
+
+/* Last error message of the calling thread ("" if none). */
+const char* msgl_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * KV-pool store.
+ * Replaces MHAKVPool.set_kv_buffer (mini_sglang/mem_cache/token2kv.py:133-142):
+ *   k_cache[loc[t]] = k[t]; v_cache[loc[t]] = v[t]   for t in [0, T).
+ * k, v: [T, Hkv, D] bf16 with row strides k_stride / v_stride (v is a strided
+ * view of the qkv GEMM output in the reference, qwen3.py:87, attention.py:32);
+ * k_cache, v_cache: [slots, Hkv, D] bf16 with slot stride cache_stride.
+ * loc: int32 [T] (BatchInfo.out_cache_loc).  Duplicate slots (graph padding rows
+ * all target dummy slot 0, cuda_graph_runner.py:142-151) race benignly.
+ * ------------------------------------------------------------------------- */
+int msgl_store_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stride,
+                  const int32_t* loc, void* k_cache, void* v_cache, int64_t cache_stride,
+                  int T, int Hkv, int D, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Paged decode attention (one query token per request).
+ * Replaces TorchNativeAttnBackend._run_sdpa_forward_decode
+ * (mini_sglang/layers/attn/torch_attn_backend.py:114-182) and the FA3 call at
+ * fa3_attn_backend.py:136-150:
+ *   for each request b: tok = req_to_token[req_pool_indices[b], :seq_lens[b]]
+ *   out[b, h] = softmax(scale * q[b, h] . K[tok, h / (Hq/Hkv)]^T) . V[tok, h / (Hq/Hkv)]
+ * non-causal over all seq_lens[b] slots (the slot written by this step included).
+ *
+ * q:   [bs, Hq, D] bf16, request stride q_stride;  out: same shape, stride out_stride.
+ * k_cache / v_cache: [slots, Hkv, D] bf16, slot stride cache_stride.
+ * req_to_token: int32 [max_reqs, max_ctx], row stride r2t_stride
+ *   (ReqToTokenPool.req_to_token, mem_cache/req2token.py:43-45).  The kernel reads
+ *   this table directly — no per-step page-table copy.  page_size is a layout
+ *   promise: when page_size % 16 == 0, every aligned run of 16 token positions of a
+ *   request occupies 16 consecutive slots (batch_info.py:192-234, 277-291), so the
+ *   kernel reads one index per 16 tokens; any other page_size reads one per token.
+ * seq_lens, req_pool_indices: int32 [bs] (device).
+ *
+ * Split-K: the grid is fixed at bs * max_splits work groups; a request uses
+ * ceil(seq_len / chunk) of them (chunk = *chunk_dev if chunk_dev != NULL else
+ * chunk_tokens; must be a positive multiple of 16 with
+ * ceil(max seq_len / chunk) <= max_splits) and the rest exit at once, so the launch
+ * shape never depends on the sequence lengths (hipGraph replay).
+ * workspace: >= msgl_paged_decode_workspace_bytes(...) bytes of device memory,
+ *   16-byte aligned; contents are scratch.
+ * Supported: D == 128; Hq/Hkv in {1, 2, 4, 8}; Hkv in {1, 2, 4, 8}.
+ * ------------------------------------------------------------------------- */
+size_t msgl_paged_decode_workspace_bytes(int bs, int Hq, int D, int max_splits);
+
+int msgl_paged_decode(const void* q, int64_t q_stride,
+                      const void* k_cache, const void* v_cache, int64_t cache_stride,
+                      const int32_t* req_to_token, int64_t r2t_stride,
+                      const int32_t* req_pool_indices, const int32_t* seq_lens,
+                      void* out, int64_t out_stride,
+                      void* workspace, size_t workspace_bytes,
+                      int bs, int Hq, int Hkv, int D, int page_size, float scale,
+                      int max_splits, int chunk_tokens, const int32_t* chunk_dev,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Paged extend (prefill) attention, variable-length queries, bottom-right causal.
+ * Replaces TorchNativeAttnBackend._run_sdpa_forward_extend
+ * (torch_attn_backend.py:28-111) and the FA3 call at fa3_attn_backend.py:101-115:
+ *   request b owns query rows [cu_q[b], cu_q[b+1]) (Sq_b = input_seq_lens[b]);
+ *   query row i of b sits at position prefix_lens[b] + i and attends to token
+ *   positions [0, prefix_lens[b] + i] of req_to_token[req_pool_indices[b]].
+ * q / out: [sum Sq, Hq, D] bf16 (token stride q_stride / out_stride).
+ * cu_seqlens_q: int32 [bs+1] exclusive prefix sum of the per-request query counts.
+ * prefix_lens: int32 [bs].  max_seqlen_q: upper bound on Sq_b (sizes the grid).
+ * The new tokens' K/V must already be in the pool (msgl_store_kv first), as in
+ * torch_attn_backend.py:195-196.
+ * ------------------------------------------------------------------------- */
+int msgl_paged_extend(const void* q, int64_t q_stride,
+                      const void* k_cache, const void* v_cache, int64_t cache_stride,
+                      const int32_t* req_to_token, int64_t r2t_stride,
+                      const int32_t* req_pool_indices, const int32_t* cu_seqlens_q,
+                      const int32_t* prefix_lens,
+                      void* out, int64_t out_stride,
+                      int bs, int max_seqlen_q, int Hq, int Hkv, int D, int page_size,
+                      float scale, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * RMSNorm.  Replaces RMSNorm.forward(x) (mini_sglang/layers/layernorm.py:39-50,
+ * residual is None):  out = bf16( x_f32 * rsqrt(mean(x_f32^2) + eps) * w_f32 ).
+ * x: [rows, cols] bf16 with row stride x_stride (q/k-norm rows are 128-wide slices of
+ * the qkv output, qwen3.py:88-93); out row stride out_stride; w: [cols] bf16.
+ * cols % 8 == 0, cols <= 16384.  out may alias x.
+ * ------------------------------------------------------------------------- */
+int msgl_rmsnorm(const void* x, int64_t x_stride, const void* w, void* out, int64_t out_stride,
+                 int rows, int cols, float eps, void* stream);
+
+/* Fused residual-add RMSNorm, in place on both tensors.  Replaces
+ * RMSNorm.forward(x, residual) (layernorm.py:41-49; in-place form 33-35):
+ *   s = x_f32 + residual_f32; residual = bf16(s);
+ *   x = bf16( s * rsqrt(mean(s^2) + eps) * w_f32 )   (norm uses the UNROUNDED s).
+ * x, residual: [rows, cols] bf16 contiguous rows (stride = cols). */
+int msgl_fused_add_rmsnorm(void* x, void* residual, const void* w,
+                           int rows, int cols, float eps, void* stream);
+
+/* SiLU-gate.  Replaces SiluAndMul.forward (mini_sglang/layers/activation.py:12-14):
+ *   out[r, c] = bf16( bf16(silu_f32(x[r, c])) * x[r, n + c] ),  c in [0, n).
+ * x: [rows, 2n] bf16 with row stride x_stride; out: [rows, n] contiguous.  n % 8 == 0. */
+int msgl_silu_and_mul(const void* x, int64_t x_stride, void* out, int rows, int n, void* stream);
+
+/* Neox rotary embedding, in place on q and k.  Replaces RotaryEmbedding.forward
+ * (mini_sglang/layers/rotary_embedding.py:70-95; table layout 59-67):
+ *   cos = cache[pos, :D/2], sin = cache[pos, D/2:]  (fp32 table [max_pos, D])
+ *   y1 = x1*cos - x2*sin ; y2 = x1*sin + x2*cos,  x1 = x[..., :D/2], x2 = x[..., D/2:].
+ * rounding: 0 = reproduce the reference's torch fallback bit for bit (cos/sin rounded
+ *   to bf16 and every multiply / add rounded to bf16, rotary_embedding.py:28-33);
+ *   1 = fp32 arithmetic with one final rounding (what sgl_kernel's kernel does,
+ *   rotary_embedding.py:77-84).
+ * positions: int32 [T]; q: [T, Hq, D] token stride q_stride; k: [T, Hkv, D] stride k_stride. */
+int msgl_rope_neox(const int32_t* positions, void* q, int64_t q_stride, void* k, int64_t k_stride,
+                   const float* cos_sin_cache, int T, int Hq, int Hkv, int D, int rounding,
+                   void* stream);
+
+/* Fused per-head q/k RMSNorm -> neox RoPE -> KV-pool store for one layer's qkv GEMM
+ * output.  Replaces the op sequence at mini_sglang/models/qwen3.py:88-94 plus
+ * set_kv_buffer (token2kv.py:141-142), with each stage rounded to bf16 exactly where the
+ * unfused reference ops round.
+ *   qkv: [T, (Hq + 2*Hkv) * D] bf16, token stride qkv_stride; q and k parts are
+ *   normalised and rotated IN PLACE; the rotated k and the untouched v are copied to
+ *   k_cache / v_cache at slot loc[t] (skipped when loc == NULL). */
+int msgl_qknorm_rope_store(void* qkv, int64_t qkv_stride, const void* q_norm_w, const void* k_norm_w,
+                           float eps, const int32_t* positions, const float* cos_sin_cache,
+                           const int32_t* loc, void* k_cache, void* v_cache, int64_t cache_stride,
+                           int T, int Hq, int Hkv, int D, int rounding, void* stream);
+
+/* Greedy sampling helper: out[b] = argmax_j logits[b, j] over fp32(logits), first index
+ * on ties.  Replaces the temperature == 0 branch of Sampler.forward
+ * (mini_sglang/layers/sampler.py:14-15, 23).  logits: [bs, vocab] bf16 or fp32
+ * (elem_bytes 2 or 4), row stride in elements; out: int32 [bs]. */
+int msgl_argmax(const void* logits, int64_t row_stride, int elem_bytes, int32_t* out,
+                int bs, int vocab, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSGL_HIP_H */

@@ -1,0 +1,143 @@
+"""``--attention_backend hip``: paged attention on hand-written gfx950 kernels.
+
+Plugs in where the reference selects a backend by name (mini_sglang/managers/model_runner.py:107-128)
+and is constructed the same way, ``HipAttnBackend(model_runner)``, reading ``device``,
+``req_to_token_pool``, ``kv_cache_pool``, ``page_size`` and ``model_config.max_context_len`` from it
+(compare mini_sglang/layers/attn/fa3_attn_backend.py:34-41).
+
+Differences from the FA3 backend that matter to a caller:
+  * no page-table copy: the kernels read ``req_to_token`` + ``req_pool_indices`` + ``seq_lens``
+    directly, so the per-forward metadata is two integers (decode) or one prefix sum (extend), and the
+    graph-replay hook only refreshes the split size in a 4-byte device word;
+  * page ids are never read from ``req_to_page`` (its writer is wrong for multi-page prefixes,
+    mini_sglang/mem_cache/req2token.py:86-91); ``req_to_token`` is the only table used;
+  * q may be a row-strided view of the qkv GEMM output (no ``.contiguous()`` copy).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from .. import ops
+from .attn_backend import AttentionBackend
+
+
+@dataclass
+class HipAttnMetadata:
+    # decode
+    max_splits: int = 1
+    chunk_tokens: int = 0
+    chunk_dev: Optional[torch.Tensor] = None
+    # extend
+    cu_seqlens_q: Optional[torch.Tensor] = None
+    max_seqlen_q: int = 0
+
+
+def splits_for_batch(bs: int) -> int:
+    """Upper bound on splits per request: enough work groups (bs * splits ~ 2048) to fill 256 CUs a few
+    times over at small batch, 1 at large batch where requests alone fill the chip."""
+    return max(1, min(512, -(-2048 // max(bs, 1))))
+
+
+class HipAttnBackend(AttentionBackend):
+    def __init__(self, model_runner):
+        super().__init__()
+        self.forward_metadata: Optional[HipAttnMetadata] = None
+        self.device = model_runner.device
+        self.req_to_token_pool = model_runner.req_to_token_pool
+        self.kv_cache_pool = model_runner.kv_cache_pool
+        self.page_size = model_runner.page_size
+        self.max_context_len = model_runner.model_config.max_context_len
+        self._workspace: Optional[torch.Tensor] = None
+        self.decode_graph_vars: Optional[dict] = None
+        self.decode_graph_metadata: Dict[int, HipAttnMetadata] = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _workspace_for(self, bs: int, Hq: int, D: int, max_splits: int) -> Optional[torch.Tensor]:
+        if max_splits <= 1:
+            return None
+        need = ops.decode_workspace_bytes(bs, Hq, D, max_splits)
+        if self._workspace is None or self._workspace.numel() < need:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("decode workspace must be sized before graph capture (init_cuda_graph_state)")
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._workspace
+
+    @staticmethod
+    def _decode_split(seq_lens_cpu: torch.Tensor, bs: int, max_splits: int) -> int:
+        return ops.pick_split(int(seq_lens_cpu.max()), int(seq_lens_cpu.sum()), bs, max_splits)
+
+    # ------------------------------------------------------------------ eager metadata
+    def init_forward_metadata(self, batch):
+        md = HipAttnMetadata()
+        bs = batch.seq_lens.numel()
+        if batch.forward_mode.is_decode():
+            md.max_splits = splits_for_batch(bs)
+            md.chunk_tokens = self._decode_split(batch.seq_lens_cpu, bs, md.max_splits)
+        else:
+            md.max_seqlen_q = int(batch.input_seq_lens_max)
+            md.cu_seqlens_q = torch.nn.functional.pad(torch.cumsum(batch.input_seq_lens, dim=0, dtype=torch.int32), (1, 0))
+        self.forward_metadata = md
+
+    # ------------------------------------------------------------------ forward
+    def forward_extend(self, q, k, v, layer, batch, save_kv_cache: bool = True):
+        if save_kv_cache:
+            self.kv_cache_pool.set_kv_buffer(layer, batch.out_cache_loc, k, v)
+        md = self.forward_metadata
+        k_cache, v_cache = self.kv_cache_pool.get_kv_buffer(layer.layer_id)
+        T = q.shape[0]
+        o = ops.paged_extend(
+            _as_heads(q, layer.num_heads, layer.head_dim), k_cache, v_cache, self.req_to_token_pool.req_to_token,
+            batch.req_pool_indices, md.cu_seqlens_q, batch.prefix_seq_lens, md.max_seqlen_q, layer.scale, self.page_size)
+        return o.view(T, layer.num_heads * layer.head_dim)
+
+    def forward_decode(self, q, k, v, layer, batch, save_kv_cache: bool = True):
+        if save_kv_cache:
+            self.kv_cache_pool.set_kv_buffer(layer, batch.out_cache_loc, k, v)
+        md = self.forward_metadata
+        k_cache, v_cache = self.kv_cache_pool.get_kv_buffer(layer.layer_id)
+        bs = q.shape[0]
+        o = ops.paged_decode(
+            _as_heads(q, layer.num_heads, layer.head_dim), k_cache, v_cache, self.req_to_token_pool.req_to_token,
+            batch.req_pool_indices, batch.seq_lens, layer.scale, self.page_size,
+            workspace=self._workspace_for(bs, layer.num_heads, layer.head_dim, md.max_splits),
+            max_splits=md.max_splits, chunk_tokens=md.chunk_tokens, chunk_dev=md.chunk_dev)
+        return o.view(bs, layer.num_heads * layer.head_dim)
+
+    # ------------------------------------------------------------------ graph hooks
+    def init_cuda_graph_state(self, max_bs: int, num_heads: Optional[int] = None, head_dim: int = 128):
+        """Static state shared by all captured batch sizes: the 4-byte split-size word and a workspace large
+        enough for every (bs, splits_for_batch(bs)) pair (compare fa3_attn_backend.py:154-175)."""
+        self.decode_graph_vars = {"chunk": torch.full((1,), 1 << 20, dtype=torch.int32, device=self.device)}
+        self.decode_graph_metadata = {}
+        if num_heads is None:
+            num_heads = getattr(self, "graph_num_heads", None)
+        if num_heads is not None:
+            worst = max(ops.decode_workspace_bytes(bs, num_heads, head_dim, splits_for_batch(bs)) for bs in range(1, max_bs + 1))
+            self._workspace = torch.empty(worst, dtype=torch.uint8, device=self.device)
+
+    def init_forward_metadata_capture_cuda_graph(self, bs: int, forward_mode):
+        if forward_mode.is_extend():
+            raise NotImplementedError("extend is not captured in a graph")
+        md = HipAttnMetadata(max_splits=splits_for_batch(bs), chunk_dev=self.decode_graph_vars["chunk"])
+        self.decode_graph_metadata[bs] = md
+        self.forward_metadata = md
+
+    def init_forward_metadata_replay_cuda_graph(self, bs: int, req_pool_indices: torch.Tensor, seq_lens: torch.Tensor,
+                                                seq_lens_cpu: torch.Tensor, forward_mode):
+        """The kernels read req_pool_indices / seq_lens from the runner's static buffers; only the split size
+        depends on the batch, and it lives in one device word (compare fa3_attn_backend.py:203-233, which
+        copies a [bs, max_ctx] table every step)."""
+        md = self.decode_graph_metadata[bs]
+        if forward_mode.is_decode():
+            # padded rows have length 1; they only lower the average, never the maximum
+            chunk = self._decode_split(seq_lens_cpu, bs, md.max_splits)
+            self.decode_graph_vars["chunk"].fill_(chunk)
+        self.forward_metadata = md
+
+
+def _as_heads(q: torch.Tensor, num_heads: int, head_dim: int) -> torch.Tensor:
+    """[T, H*D] (possibly a row-strided view) -> [T, H, D] without copying."""
+    return q.view(q.shape[0], num_heads, head_dim) if q.dim() == 2 else q

@@ -1,0 +1,27 @@
+// Error plumbing and version query of libmsgl_hip.so.
+#include "msgl_common.h"
+
+namespace msgl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// Launch errors (bad configuration, missing code object) surface here; execution faults
+// surface at the caller's next synchronisation, as with any asynchronous HIP work.
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return MSGL_OK;
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return MSGL_E_LAUNCH;
+}
+
+}  // namespace msgl
+
+extern "C" int msgl_abi_version(void) { return 1; }
+extern "C" const char* msgl_last_error(void) { return msgl::g_err; }

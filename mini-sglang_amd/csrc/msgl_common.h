@@ -1,0 +1,78 @@
+// Shared device helpers and host-side error plumbing for libmsgl_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/msgl_hip.h"
+
+namespace msgl {
+
+// ---- host side -------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define MSGL_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            ::msgl::set_error(__VA_ARGS__); \
+            return MSGL_E_INVALID;         \
+        }                                  \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- device side -----------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+// bf16 <-> f32 on raw bits.  A bf16 is the upper half of the f32 with the same value.
+__device__ __forceinline__ float bf16_lo(uint32_t packed) { return __builtin_bit_cast(float, packed << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t packed) { return __builtin_bit_cast(float, packed & 0xffff0000u); }
+
+// Round-to-nearest-even f32 -> bf16 bits; NaN stays NaN (hardware v_cvt_pk_bf16_f32).
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    bf16x2_t r;
+    r[0] = (__bf16)lo;
+    r[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, r);
+}
+// Value of x after one rounding to bf16 (what a torch bf16 elementwise op returns).
+__device__ __forceinline__ float round_bf16(float x) { return (float)(__bf16)x; }
+
+// a.lo*b.lo + a.hi*b.hi + c on packed bf16 pairs, f32 accumulate (v_dot2c_f32_bf16).
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+
+// DPP lane movement inside a row of 16 lanes; fuses into the consuming VALU op.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+// Sum over the 16 lanes of a DPP row; every lane of the row gets the total.
+__device__ __forceinline__ float row16_sum(float x) {
+    x += dpp_f32<DPP_XOR1>(x);
+    x += dpp_f32<DPP_XOR2>(x);
+    x += dpp_f32<DPP_ROW_HALF_MIRROR>(x);  // quads hold equal values: mirror == xor 4
+    x += dpp_f32<DPP_ROW_MIRROR>(x);       // halves hold equal values: mirror == xor 8
+    return x;
+}
+
+// Sum over all 64 lanes of a wave; every lane gets the total.
+__device__ __forceinline__ float wave_sum(float x) {
+    x = row16_sum(x);
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    return x;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+}  // namespace msgl

@@ -1,0 +1,381 @@
+// Paged decode attention for gfx950: one query token per request, K/V gathered from the
+// slot pool through req_to_token.  HBM-bandwidth bound (G flop per byte, G = Hq/Hkv <= 8),
+// so the kernel is built around the load stream, not the arithmetic:
+//
+//   * a work group (8 waves) owns one (request, split) pair and ALL local kv heads, so the
+//     waves of a group together read whole token rows ([Hkv, 128] bf16 = up to 2 KiB
+//     contiguous) and whole pages;
+//   * a wave owns one kv head and walks its share of the split in tiles of 16 tokens.  One
+//     global_load_dwordx4 per lane covers 4 tokens: the 16 lanes of a DPP row read one
+//     256-byte K (or V) row, the 4 rows of the wave read 4 tokens;
+//   * K and V tiles live in VGPRs (no LDS round trip: nothing is shared between waves).
+//     The next tile's K loads are issued as soon as the scores of the current tile are
+//     formed, the next V loads as soon as P.V is done, and the slot indices are fetched
+//     two tiles ahead, so every wave keeps 4-8 KiB in flight;
+//   * the G query heads of the kv head stay in registers as packed bf16 and feed
+//     v_dot2c_f32_bf16; partial dot products are summed across the 16 lanes of a row with
+//     DPP adds (no LDS, no ds_bpermute);
+//   * each DPP row keeps its own online-softmax state (running max, sum, 8 output
+//     columns per lane and head) — rows are merged once, after the loop, and waves that
+//     share a kv head are merged through LDS;
+//   * split-K over the sequence: the grid is always bs * max_splits groups and a request
+//     uses ceil(seq_len / chunk) of them, so the launch shape is independent of the
+//     sequence lengths; partial results go to a caller-provided workspace and a second
+//     small kernel merges them (requests that fit one split are written directly).
+#include "msgl_common.h"
+
+namespace msgl {
+
+constexpr int kTile = 16;    // tokens per wave iteration
+constexpr int kWaves = 8;    // waves per work group
+constexpr int kD = 128;      // head dim
+constexpr float kNegBig = -1.0e30f;
+
+struct DecodeParams {
+    const uint16_t* q;
+    int64_t q_stride;
+    const uint16_t* kc;
+    const uint16_t* vc;
+    int64_t cache_stride;
+    const int32_t* r2t;
+    int64_t r2t_stride;
+    const int32_t* req_idx;
+    const int32_t* seq_lens;
+    uint16_t* out;
+    int64_t out_stride;
+    float* ws_o;   // [bs, max_splits, Hq, 128] unnormalised partial outputs
+    float* ws_ml;  // [bs, max_splits, Hq, 2]   (running max in log2 units, running sum)
+    const int32_t* chunk_dev;
+    int chunk;
+    int bs, Hq, max_splits;
+    float scale_log2e;
+};
+
+// Tokens per split: a positive multiple of the tile so that tiles never straddle a page.
+__device__ __forceinline__ int split_chunk(const DecodeParams& p) {
+    const int c = p.chunk_dev ? *p.chunk_dev : p.chunk;
+    return max(kTile, (c + kTile - 1) & ~(kTile - 1));
+}
+
+__device__ __forceinline__ uint4 ld16(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// Slots of the 4 tokens this lane's row handles in tile `tile` of the split [t0, t1).
+// PAGED16: one table read per tile (16 consecutive slots); otherwise one per token.
+// Tokens past the end map to slot 0, the pool's always-allocated dummy page.
+template <bool PAGED16>
+__device__ __forceinline__ void fetch_slots(const int32_t* r2t_row, int t0, int t1, int tile, int ntiles, int j,
+                                            int (&slot)[4]) {
+    const int tok0 = t0 + tile * kTile;
+    if (PAGED16) {
+        int base = 0;
+        if (tile < ntiles) base = r2t_row[tok0];
+        base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) slot[i] = (tile < ntiles) ? base + i * 4 + j : 0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tok = tok0 + i * 4 + j;
+            slot[i] = (tok < t1) ? r2t_row[tok] : 0;
+        }
+    }
+}
+
+template <int G, int HPB, bool PAGED16>
+__global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams p) {
+    constexpr int WPH = kWaves / HPB;  // waves sharing one kv head
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lds_o = reinterpret_cast<float*>(smem);                       // [kWaves][G][128]
+    float* lds_ml = lds_o + kWaves * G * kD;                             // [kWaves][G][2]
+
+    const int b = blockIdx.x / p.max_splits;
+    const int split = blockIdx.x - b * p.max_splits;
+    const int S = p.seq_lens[b];
+    const int chunk = split_chunk(p);
+    const int nsplit = min((S + chunk - 1) / chunk, p.max_splits);
+    if (split >= nsplit) return;
+    const int t0 = split * chunk;
+    const int t1 = (split == p.max_splits - 1) ? S : min(S, t0 + chunk);  // last split takes the tail
+    const int ntiles = (t1 - t0 + kTile - 1) / kTile;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane >> 4;   // DPP row = token within a group of 4
+    const int c = lane & 15;   // 16-byte column chunk of the 256-byte head row
+    const int h = wave / WPH;  // local kv head
+    const int sub = wave - h * WPH;
+
+    const int32_t* r2t_row = p.r2t + (int64_t)p.req_idx[b] * p.r2t_stride;
+    const uint16_t* kbase = p.kc + h * kD + c * 8;
+    const uint16_t* vbase = p.vc + h * kD + c * 8;
+
+    uint4 qv[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) qv[g] = ld16(p.q + (int64_t)b * p.q_stride + (h * G + g) * kD + c * 8);
+
+    float m[G], l[G], acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = kNegBig;
+        l[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+    }
+
+    int tile = sub;
+    int slot_cur[4], slot_nxt[4], slot_nn[4];
+    fetch_slots<PAGED16>(r2t_row, t0, t1, tile, ntiles, j, slot_cur);
+    fetch_slots<PAGED16>(r2t_row, t0, t1, tile + WPH, ntiles, j, slot_nxt);
+    uint4 kk[4], vv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kk[i] = ld16(kbase + (int64_t)slot_cur[i] * p.cache_stride);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vv[i] = ld16(vbase + (int64_t)slot_cur[i] * p.cache_stride);
+
+    for (; tile < ntiles; tile += WPH) {
+        // indices two tiles ahead: older than every K/V load that follows, so consuming
+        // them one iteration later never waits on younger loads
+        fetch_slots<PAGED16>(r2t_row, t0, t1, tile + 2 * WPH, ntiles, j, slot_nn);
+
+        const int tok0 = t0 + tile * kTile + j;
+        float s[G][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float d = dot2_bf16(qv[g].x, kk[i].x, 0.f);
+                d = dot2_bf16(qv[g].y, kk[i].y, d);
+                d = dot2_bf16(qv[g].z, kk[i].z, d);
+                d = dot2_bf16(qv[g].w, kk[i].w, d);
+                d = row16_sum(d);
+                s[g][i] = (tok0 + i * 4 < t1) ? d * p.scale_log2e : -INFINITY;
+            }
+        }
+        // K registers are free: next tile's K goes in flight under the softmax + P.V work
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kk[i] = ld16(kbase + (int64_t)slot_nxt[i] * p.cache_stride);
+
+        float pr[G][4];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float mt = fmaxf(fmaxf(s[g][0], s[g][1]), fmaxf(s[g][2], s[g][3]));
+            const float mn = fmaxf(m[g], mt);
+            const float alpha = fast_exp2(m[g] - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pr[g][i] = fast_exp2(s[g][i] - mn);
+                ps += pr[g][i];
+            }
+            l[g] = l[g] * alpha + ps;
+            m[g] = mn;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[g][e] *= alpha;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t w[4] = {vv[i].x, vv[i].y, vv[i].z, vv[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = bf16_lo(w[e]), hi = bf16_hi(w[e]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    acc[g][2 * e] = fmaf(pr[g][i], lo, acc[g][2 * e]);
+                    acc[g][2 * e + 1] = fmaf(pr[g][i], hi, acc[g][2 * e + 1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vv[i] = ld16(vbase + (int64_t)slot_nxt[i] * p.cache_stride);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) slot_nxt[i] = slot_nn[i];
+    }
+
+    // merge the 4 DPP rows of the wave (tokens were dealt round-robin to rows)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float M = fmaxf(m[g], __shfl_xor(m[g], 16));
+        M = fmaxf(M, __shfl_xor(M, 32));
+        const float w = fast_exp2(m[g] - M);
+        float lg = l[g] * w;
+        lg += __shfl_xor(lg, 16);
+        lg += __shfl_xor(lg, 32);
+        l[g] = lg;
+        m[g] = M;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = acc[g][e] * w;
+            a += __shfl_xor(a, 16);
+            a += __shfl_xor(a, 32);
+            acc[g][e] = a;
+        }
+    }
+    if (j == 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float* dst = lds_o + (wave * G + g) * kD + c * 8;
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[g][4], acc[g][5], acc[g][6], acc[g][7]);
+            if (c == 0) {
+                lds_ml[(wave * G + g) * 2] = m[g];
+                lds_ml[(wave * G + g) * 2 + 1] = l[g];
+            }
+        }
+    }
+    __syncthreads();
+    if (sub != 0) return;
+
+    // the first wave of every kv head merges the WPH partial states and writes the result
+    const bool final_out = (nsplit == 1);
+#pragma unroll
+    for (int idx = lane * 2; idx < G * kD; idx += 128) {
+        const int g = idx / kD, d = idx - g * kD;
+        float M = kNegBig;
+#pragma unroll
+        for (int w = 0; w < WPH; ++w) M = fmaxf(M, lds_ml[((h * WPH + w) * G + g) * 2]);
+        float L = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPH; ++w) {
+            const int ww = h * WPH + w;
+            const float f = fast_exp2(lds_ml[(ww * G + g) * 2] - M);
+            L += f * lds_ml[(ww * G + g) * 2 + 1];
+            const float2 o = *reinterpret_cast<const float2*>(lds_o + (ww * G + g) * kD + d);
+            o0 += f * o.x;
+            o1 += f * o.y;
+        }
+        const int hq = h * G + g;
+        if (final_out) {
+            const float inv = 1.0f / L;
+            *reinterpret_cast<uint32_t*>(p.out + (int64_t)b * p.out_stride + hq * kD + d) = pack_bf16(o0 * inv, o1 * inv);
+        } else {
+            const int64_t row = ((int64_t)b * p.max_splits + split) * p.Hq + hq;
+            *reinterpret_cast<float2*>(p.ws_o + row * kD + d) = make_float2(o0, o1);
+            if (d == 0) *reinterpret_cast<float2*>(p.ws_ml + row * 2) = make_float2(M, L);
+        }
+    }
+}
+
+// Merge the split-K partials of one (request, query head); 64 lanes x 2 columns.
+__global__ __launch_bounds__(64) void paged_decode_merge_kernel(DecodeParams p) {
+    const int b = blockIdx.x / p.Hq;
+    const int hq = blockIdx.x - b * p.Hq;
+    const int S = p.seq_lens[b];
+    const int chunk = split_chunk(p);
+    const int nsplit = min((S + chunk - 1) / chunk, p.max_splits);
+    if (nsplit <= 1) return;  // written directly by the main kernel
+    const int d = threadIdx.x * 2;
+    const int64_t row0 = ((int64_t)b * p.max_splits) * p.Hq + hq;
+    float M = kNegBig;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, p.ws_ml[(row0 + (int64_t)s * p.Hq) * 2]);
+    float L = 0.f, o0 = 0.f, o1 = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const int64_t row = row0 + (int64_t)s * p.Hq;
+        const float2 ml = *reinterpret_cast<const float2*>(p.ws_ml + row * 2);
+        const float f = fast_exp2(ml.x - M);
+        L += f * ml.y;
+        const float2 o = *reinterpret_cast<const float2*>(p.ws_o + row * kD + d);
+        o0 += f * o.x;
+        o1 += f * o.y;
+    }
+    const float inv = 1.0f / L;
+    *reinterpret_cast<uint32_t*>(p.out + (int64_t)b * p.out_stride + hq * kD + d) = pack_bf16(o0 * inv, o1 * inv);
+}
+
+template <int G, int HPB>
+static int launch_decode(const DecodeParams& p, int page_size, hipStream_t stream) {
+    const dim3 grid(p.bs * p.max_splits), block(kWaves * 64);
+    const size_t lds = (size_t)kWaves * G * (kD + 2) * sizeof(float);
+    if (page_size % kTile == 0)
+        hipLaunchKernelGGL((paged_decode_kernel<G, HPB, true>), grid, block, lds, stream, p);
+    else
+        hipLaunchKernelGGL((paged_decode_kernel<G, HPB, false>), grid, block, lds, stream, p);
+    int rc = check_launch("paged_decode_kernel");
+    if (rc) return rc;
+    if (p.max_splits > 1) {
+        hipLaunchKernelGGL(paged_decode_merge_kernel, dim3(p.bs * p.Hq), dim3(64), 0, stream, p);
+        rc = check_launch("paged_decode_merge_kernel");
+    }
+    return rc;
+}
+
+template <int G>
+static int dispatch_hpb(const DecodeParams& p, int Hkv, int page_size, hipStream_t stream) {
+    switch (Hkv) {
+        case 1: return launch_decode<G, 1>(p, page_size, stream);
+        case 2: return launch_decode<G, 2>(p, page_size, stream);
+        case 4: return launch_decode<G, 4>(p, page_size, stream);
+        case 8: return launch_decode<G, 8>(p, page_size, stream);
+    }
+    set_error("msgl_paged_decode: Hkv=%d unsupported (1, 2, 4 or 8 local kv heads)", Hkv);
+    return MSGL_E_INVALID;
+}
+
+}  // namespace msgl
+
+using namespace msgl;
+
+extern "C" size_t msgl_paged_decode_workspace_bytes(int bs, int Hq, int D, int max_splits) {
+    if (bs <= 0 || Hq <= 0 || D <= 0 || max_splits <= 0) return 0;
+    return (size_t)bs * max_splits * Hq * (D + 2) * sizeof(float);
+}
+
+extern "C" int msgl_paged_decode(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                                 int64_t cache_stride, const int32_t* req_to_token, int64_t r2t_stride,
+                                 const int32_t* req_pool_indices, const int32_t* seq_lens, void* out,
+                                 int64_t out_stride, void* workspace, size_t workspace_bytes, int bs, int Hq, int Hkv,
+                                 int D, int page_size, float scale, int max_splits, int chunk_tokens,
+                                 const int32_t* chunk_dev, void* stream) {
+    if (bs == 0) return MSGL_OK;
+    MSGL_REQUIRE(bs > 0, "msgl_paged_decode: bs=%d", bs);
+    MSGL_REQUIRE(D == kD, "msgl_paged_decode: head dim %d unsupported (128 only)", D);
+    MSGL_REQUIRE(Hkv > 0 && Hq % Hkv == 0, "msgl_paged_decode: Hq=%d not a multiple of Hkv=%d", Hq, Hkv);
+    MSGL_REQUIRE(page_size >= 1, "msgl_paged_decode: page_size=%d", page_size);
+    MSGL_REQUIRE(max_splits >= 1 && max_splits <= 4096, "msgl_paged_decode: max_splits=%d", max_splits);
+    MSGL_REQUIRE(chunk_dev != nullptr || (chunk_tokens > 0 && chunk_tokens % kTile == 0),
+                 "msgl_paged_decode: chunk_tokens=%d must be a positive multiple of %d", chunk_tokens, kTile);
+    MSGL_REQUIRE(q && k_cache && v_cache && req_to_token && req_pool_indices && seq_lens && out,
+                 "msgl_paged_decode: null pointer argument");
+    MSGL_REQUIRE(aligned16(q) && aligned16(k_cache) && aligned16(v_cache) && aligned16(out),
+                 "msgl_paged_decode: q, k_cache, v_cache and out must be 16-byte aligned");
+    MSGL_REQUIRE(q_stride % 8 == 0 && cache_stride % 8 == 0 && out_stride % 2 == 0,
+                 "msgl_paged_decode: strides must keep 16-byte row alignment");
+    MSGL_REQUIRE(q_stride >= (int64_t)Hq * D && out_stride >= (int64_t)Hq * D && cache_stride >= (int64_t)Hkv * D,
+                 "msgl_paged_decode: stride smaller than a row");
+    const size_t need = msgl_paged_decode_workspace_bytes(bs, Hq, D, max_splits);
+    if (max_splits > 1) {
+        if (!workspace || workspace_bytes < need || !aligned16(workspace)) {
+            set_error("msgl_paged_decode: workspace of %zu bytes (16-byte aligned) required, got %zu", need,
+                      workspace_bytes);
+            return MSGL_E_WORKSPACE;
+        }
+    }
+    DecodeParams p;
+    p.q = static_cast<const uint16_t*>(q);
+    p.q_stride = q_stride;
+    p.kc = static_cast<const uint16_t*>(k_cache);
+    p.vc = static_cast<const uint16_t*>(v_cache);
+    p.cache_stride = cache_stride;
+    p.r2t = req_to_token;
+    p.r2t_stride = r2t_stride;
+    p.req_idx = req_pool_indices;
+    p.seq_lens = seq_lens;
+    p.out = static_cast<uint16_t*>(out);
+    p.out_stride = out_stride;
+    p.ws_o = static_cast<float*>(workspace);
+    p.ws_ml = p.ws_o ? p.ws_o + (size_t)bs * max_splits * Hq * D : nullptr;
+    p.chunk_dev = chunk_dev;
+    p.chunk = chunk_tokens;
+    p.bs = bs;
+    p.Hq = Hq;
+    p.max_splits = max_splits;
+    p.scale_log2e = scale * 1.4426950408889634f;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (Hq / Hkv) {
+        case 1: return dispatch_hpb<1>(p, Hkv, page_size, st);
+        case 2: return dispatch_hpb<2>(p, Hkv, page_size, st);
+        case 4: return dispatch_hpb<4>(p, Hkv, page_size, st);
+        case 8: return dispatch_hpb<8>(p, Hkv, page_size, st);
+    }
+    set_error("msgl_paged_decode: Hq/Hkv=%d unsupported (1, 2, 4 or 8)", Hq / Hkv);
+    return MSGL_E_INVALID;
+}

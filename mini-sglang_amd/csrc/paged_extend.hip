@@ -1,0 +1,253 @@
+// Paged extend (prefill) attention for gfx950: variable-length query runs, bottom-right
+// causal mask, K/V gathered from the slot pool through req_to_token.  MFMA bound.
+//
+// Work group = 4 waves = 128 consecutive query rows of one (request, query head); every
+// wave owns 32 rows.  The key axis is walked in tiles of 64 tokens staged in LDS:
+//   S^T = K . Q^T      v_mfma_f32_32x32x16_bf16, A = K rows from LDS (ds_read_b128 on an
+//                      XOR-swizzled image), B = Q^T held in registers for the whole kernel;
+//                      the accumulator has the QUERY on the lane and 16 KEYS in registers,
+//                      so row max / row sum are in-lane plus one exchange with lane ^ 32;
+//   O^T += V^T . P^T   the S^T accumulator, exponentiated and packed to bf16, is already
+//                      the B operand (its register order fixes the key order inside a
+//                      k-step); the matching A operand V^T comes from LDS through
+//                      ds_read_b64_tr_b16 (hardware transpose) on a 320-byte-stride image
+//                      that is bank-conflict free for that read.
+// The next tile's rows are fetched into registers before the MFMAs of the current tile
+// and written to LDS after them, so HBM/L2 latency hides under the matrix work.
+#include "msgl_common.h"
+
+namespace msgl {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int kBM = 128;          // query rows per work group
+constexpr int kBN = 64;           // keys per LDS tile
+constexpr int kHD = 128;          // head dim
+constexpr int kKRow = 256;        // bytes per K row in LDS (swizzled 16-byte chunks)
+constexpr int kVRow = 320;        // bytes per V row in LDS (padded: conflict-free transposed reads)
+constexpr float kNegBigE = -1.0e30f;
+
+struct ExtendParams {
+    const uint16_t* q;
+    int64_t q_stride;
+    const uint16_t* kc;
+    const uint16_t* vc;
+    int64_t cache_stride;
+    const int32_t* r2t;
+    int64_t r2t_stride;
+    const int32_t* req_idx;
+    const int32_t* cu_q;
+    const int32_t* prefix;
+    uint16_t* out;
+    int64_t out_stride;
+    int tiles_per_req;
+    int group;  // query heads per kv head
+    float scale_log2e;
+};
+
+__device__ __forceinline__ bf16x8_t as_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
+
+__global__ __launch_bounds__(256) void paged_extend_kernel(ExtendParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[kBN * kKRow + kBN * kVRow];
+    char* lds_k = lds;
+    char* lds_v = lds + kBN * kKRow;
+
+    const int b = blockIdx.x / p.tiles_per_req;
+    const int qt = blockIdx.x - b * p.tiles_per_req;
+    const int hq = blockIdx.y;
+    const int hk = hq / p.group;
+    const int q0 = p.cu_q[b];
+    const int Sq = p.cu_q[b + 1] - q0;
+    if (qt * kBM >= Sq) return;
+    const int prefix = p.prefix[b];
+    const int kv_len = min(prefix + Sq, prefix + qt * kBM + kBM);  // keys any row of this block may see
+    const int nkt = (kv_len + kBN - 1) / kBN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31;  // query column of the S^T / O^T tiles
+    const int h = lane >> 5;
+    const int row0 = qt * kBM + wave * 32;  // first query row of this wave
+    const int qrow = row0 + n;
+    const bool qvalid = qrow < Sq;
+    const int qpos = prefix + qrow;  // last key position this lane's query may see
+
+    const int32_t* r2t_row = p.r2t + (int64_t)p.req_idx[b] * p.r2t_stride;
+
+    // Q^T fragments: B operand, lane (n, h) holds Q[n][16*ks + 8*h .. +8)
+    uint4 qf[8];
+    {
+        const uint16_t* qp = p.q + (int64_t)(q0 + (qvalid ? qrow : 0)) * p.q_stride + hq * kHD + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = qvalid ? *reinterpret_cast<const uint4*>(qp + ks * 16) : make_uint4(0, 0, 0, 0);
+    }
+
+    f32x16_t o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m = kNegBigE, l = 0.f;
+
+    // staging: thread owns 16-byte chunk c16 of keys skey, skey+16, skey+32, skey+48 of a tile
+    const int c16 = tid & 15;
+    const int skey = tid >> 4;
+    uint4 kst[4], vst[4];
+    auto stage_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tok = kt * kBN + skey + i * 16;
+            const int slot = (tok < kv_len) ? r2t_row[tok] : 0;  // slot 0: the pool's dummy page
+            const int64_t off = (int64_t)slot * p.cache_stride + hk * kHD + c16 * 8;
+            kst[i] = *reinterpret_cast<const uint4*>(p.kc + off);
+            vst[i] = *reinterpret_cast<const uint4*>(p.vc + off);
+        }
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = skey + i * 16;
+            *reinterpret_cast<uint4*>(lds_k + key * kKRow + ((c16 ^ (key & 15)) << 4)) = kst[i];
+            *reinterpret_cast<uint4*>(lds_v + key * kVRow + (c16 << 4)) = vst[i];
+        }
+    };
+
+    stage_load(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();  // every wave is done reading the previous tile
+        stage_write();
+        __syncthreads();
+        if (kt + 1 < nkt) stage_load(kt + 1);
+
+        const int k0 = kt * kBN;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            const int kb = k0 + sb * 32;               // first key position of this 32-key block
+            if (kb > prefix + row0 + 31) continue;     // wave-uniform: block entirely above the diagonal
+            // ---- S^T = K . Q^T ----
+            f32x16_t st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            const int key = sb * 32 + n;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const uint4 a = *reinterpret_cast<const uint4*>(lds_k + key * kKRow + (((ks * 2 + h) ^ (key & 15)) << 4));
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(qf[ks]), st, 0, 0, 0);
+            }
+            // ---- mask + online softmax (query on the lane, keys in registers) ----
+            const bool diag = (kb + 31 > prefix + row0);  // wave-uniform: some (key, query) pair is masked
+            float mx = kNegBigE;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s = st[r] * p.scale_log2e;
+                if (diag) {
+                    const int kpos = kb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    s = (kpos > qpos) ? -INFINITY : s;
+                }
+                st[r] = s;
+                mx = fmaxf(mx, s);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m, mx);
+            const float alpha = fast_exp2(m - mn);
+            m = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = fast_exp2(st[r] - mn);
+                ps += st[r];
+            }
+            l = l * alpha + ps;  // per-lane partial sum; halves are added after the loop
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            // P^T fragments: registers 8s..8s+7 are k-step s; element j is key 16s + 8(j>>2) + 4h + (j&3)
+            uint4 pf[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                pf[s] = make_uint4(pack_bf16(st[8 * s + 0], st[8 * s + 1]), pack_bf16(st[8 * s + 2], st[8 * s + 3]),
+                                   pack_bf16(st[8 * s + 4], st[8 * s + 5]), pack_bf16(st[8 * s + 6], st[8 * s + 7]));
+            // ---- O^T += V^T . P^T ----
+            const int g1 = (lane >> 4) & 1, iq = (lane & 15) >> 2, ip = lane & 3;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int kr = sb * 32 + 16 * s + 4 * h + iq;  // key row this lane addresses
+                    const char* va = lds_v + kr * kVRow + (d * 32 + 16 * g1 + 4 * ip) * 2;
+                    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) short4_t*)(va));
+                    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) short4_t*)(va + 8 * kVRow));
+                    typedef __attribute__((ext_vector_type(8))) short short8_t;
+                    short8_t a;
+                    a.lo = lo;
+                    a.hi = hi;
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), as_bf16x8(pf[s]), o[d], 0,
+                                                                   0, 0);
+                }
+            }
+        }
+    }
+
+    l += __shfl_xor(l, 32);
+    if (!qvalid) return;
+    const float inv = 1.0f / l;
+    uint16_t* op = p.out + (int64_t)(q0 + qrow) * p.out_stride + hq * kHD;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int col = d * 32 + 8 * rr + 4 * h;  // registers 4rr..4rr+3 are 4 consecutive columns
+            *reinterpret_cast<uint2*>(op + col) = make_uint2(pack_bf16(o[d][4 * rr] * inv, o[d][4 * rr + 1] * inv),
+                                                            pack_bf16(o[d][4 * rr + 2] * inv, o[d][4 * rr + 3] * inv));
+        }
+}
+
+}  // namespace msgl
+
+using namespace msgl;
+
+extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                                 int64_t cache_stride, const int32_t* req_to_token, int64_t r2t_stride,
+                                 const int32_t* req_pool_indices, const int32_t* cu_seqlens_q, const int32_t* prefix_lens,
+                                 void* out, int64_t out_stride, int bs, int max_seqlen_q, int Hq, int Hkv, int D,
+                                 int page_size, float scale, void* stream) {
+    (void)page_size;  // the table is read per token, which is valid for every page size
+    if (bs == 0 || max_seqlen_q == 0) return MSGL_OK;
+    MSGL_REQUIRE(bs > 0 && max_seqlen_q > 0, "msgl_paged_extend: bs=%d max_seqlen_q=%d", bs, max_seqlen_q);
+    MSGL_REQUIRE(D == kHD, "msgl_paged_extend: head dim %d unsupported (128 only)", D);
+    MSGL_REQUIRE(Hkv > 0 && Hq > 0 && Hq % Hkv == 0 && Hq <= 65535, "msgl_paged_extend: Hq=%d Hkv=%d", Hq, Hkv);
+    MSGL_REQUIRE(q && k_cache && v_cache && req_to_token && req_pool_indices && cu_seqlens_q && prefix_lens && out,
+                 "msgl_paged_extend: null pointer argument");
+    MSGL_REQUIRE(aligned16(q) && aligned16(k_cache) && aligned16(v_cache) && aligned16(out),
+                 "msgl_paged_extend: q, k_cache, v_cache and out must be 16-byte aligned");
+    MSGL_REQUIRE(q_stride % 8 == 0 && cache_stride % 8 == 0 && out_stride % 4 == 0,
+                 "msgl_paged_extend: strides must keep 16-byte (q, cache) / 8-byte (out) row alignment");
+    MSGL_REQUIRE(q_stride >= (int64_t)Hq * D && out_stride >= (int64_t)Hq * D && cache_stride >= (int64_t)Hkv * D,
+                 "msgl_paged_extend: stride smaller than a row");
+    ExtendParams p;
+    p.q = static_cast<const uint16_t*>(q);
+    p.q_stride = q_stride;
+    p.kc = static_cast<const uint16_t*>(k_cache);
+    p.vc = static_cast<const uint16_t*>(v_cache);
+    p.cache_stride = cache_stride;
+    p.r2t = req_to_token;
+    p.r2t_stride = r2t_stride;
+    p.req_idx = req_pool_indices;
+    p.cu_q = cu_seqlens_q;
+    p.prefix = prefix_lens;
+    p.out = static_cast<uint16_t*>(out);
+    p.out_stride = out_stride;
+    p.tiles_per_req = (max_seqlen_q + kBM - 1) / kBM;
+    p.group = Hq / Hkv;
+    p.scale_log2e = scale * 1.4426950408889634f;
+    const int64_t gx = (int64_t)bs * p.tiles_per_req;
+    MSGL_REQUIRE(gx <= 0x7fffffff, "msgl_paged_extend: grid too large");
+    hipLaunchKernelGGL(paged_extend_kernel, dim3((unsigned)gx, (unsigned)Hq), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return check_launch("paged_extend_kernel");
+}

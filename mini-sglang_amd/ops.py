@@ -1,0 +1,269 @@
+"""Tensor-level wrappers over the C ABI: shape / dtype / device checks on the host, raw device
+pointers and element strides into the library, work enqueued on torch's current stream.
+
+Every function here runs a HIP kernel; none has a torch or CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _capi
+
+_lib = _capi.lib
+_check = _capi.check
+
+DECODE_TILE = 16  # tokens per wave iteration of the decode kernel; split chunks are multiples of it
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(cond: bool, msg: str) -> None:
+    if not cond:
+        raise ValueError(msg)
+
+
+def _dev_bf16(t: torch.Tensor, name: str) -> None:
+    _need(t.is_cuda, f"{name} must live on the GPU (got {t.device})")
+    _need(t.dtype == torch.bfloat16, f"{name} must be bfloat16 (got {t.dtype})")
+
+
+def _dev_i32(t: torch.Tensor, name: str) -> None:
+    _need(t.is_cuda, f"{name} must live on the GPU (got {t.device})")
+    _need(t.dtype == torch.int32, f"{name} must be int32 (got {t.dtype})")
+    _need(t.dim() == 1 and (t.numel() <= 1 or t.stride(0) == 1), f"{name} must be a contiguous 1-D tensor")
+
+
+def _rows_view(t: torch.Tensor, name: str) -> Tuple[int, int, int]:
+    """(rows, cols, row_stride) of a 2-D tensor whose last dim is dense."""
+    _need(t.dim() == 2, f"{name} must be 2-D (got shape {tuple(t.shape)})")
+    _need(t.shape[1] == 1 or t.stride(1) == 1, f"{name}: last dim must be dense")
+    return t.shape[0], t.shape[1], (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+
+
+def _cache_stride(k_cache: torch.Tensor, v_cache: torch.Tensor, Hkv: int, D: int) -> int:
+    """Slot stride (elements) of a [slots, Hkv, D] K/V buffer pair; heads must be dense per slot.
+    Dense buffers and the [:, 0] / [:, 1] views of an interleaved [slots, 2, Hkv, D] pool both qualify."""
+    _dev_bf16(k_cache, "k_cache"), _dev_bf16(v_cache, "v_cache")
+    _need(k_cache.dim() == 3 and tuple(k_cache.shape[1:]) == (Hkv, D) and v_cache.shape == k_cache.shape,
+          "k_cache / v_cache must be [slots, Hkv, D]")
+    for t, n in ((k_cache, "k_cache"), (v_cache, "v_cache")):
+        _need(t.stride(2) == 1 and t.stride(1) == D, f"{n}: [Hkv, D] must be dense per slot")
+    _need(k_cache.stride(0) == v_cache.stride(0) and k_cache.stride(0) >= Hkv * D, "k_cache / v_cache slot strides differ")
+    return k_cache.stride(0)
+
+
+# ----------------------------------------------------------------------------- KV store
+def store_kv(k: torch.Tensor, v: torch.Tensor, loc: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor) -> None:
+    """k_cache[loc] = k; v_cache[loc] = v.  k, v: [T, Hkv, D] (row-strided views allowed)."""
+    _dev_bf16(k, "k"), _dev_bf16(v, "v")
+    _dev_i32(loc, "loc")
+    T, Hkv, D = k.shape
+    _need(v.shape == k.shape, "k and v shapes differ")
+    cs = _cache_stride(k_cache, v_cache, Hkv, D)
+    _need(loc.numel() == T, "loc length must equal the number of tokens")
+    for t, n in ((k, "k"), (v, "v")):
+        _need(t.stride(2) == 1 and t.stride(1) == D, f"{n}: heads must be dense [Hkv, D] per token")
+    ks = k.stride(0) if T > 1 else Hkv * D
+    vs = v.stride(0) if T > 1 else Hkv * D
+    _check(_lib.msgl_store_kv(k.data_ptr(), ks, v.data_ptr(), vs, loc.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                              cs, T, Hkv, D, _stream()))
+
+
+# ----------------------------------------------------------------------------- decode
+def decode_workspace_bytes(bs: int, Hq: int, D: int, max_splits: int) -> int:
+    return int(_lib.msgl_paged_decode_workspace_bytes(bs, Hq, D, max_splits))
+
+
+def paged_decode(
+    q: torch.Tensor,
+    k_cache: torch.Tensor,
+    v_cache: torch.Tensor,
+    req_to_token: torch.Tensor,
+    req_pool_indices: torch.Tensor,
+    seq_lens: torch.Tensor,
+    scale: float,
+    page_size: int,
+    *,
+    out: Optional[torch.Tensor] = None,
+    workspace: Optional[torch.Tensor] = None,
+    max_splits: int = 1,
+    chunk_tokens: int = 0,
+    chunk_dev: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """Decode attention for q [bs, Hq, D] over the paged pool; returns [bs, Hq, D] bf16."""
+    _dev_bf16(q, "q")
+    _dev_i32(req_pool_indices, "req_pool_indices"), _dev_i32(seq_lens, "seq_lens")
+    _need(q.dim() == 3 and q.stride(2) == 1 and q.stride(1) == q.shape[2], "q must be [bs, Hq, D] with dense heads")
+    bs, Hq, D = q.shape
+    _need(k_cache.dim() == 3, "k_cache must be [slots, Hkv, D]")
+    Hkv = k_cache.shape[1]
+    cs = _cache_stride(k_cache, v_cache, Hkv, D)
+    _need(req_to_token.is_cuda and req_to_token.dtype == torch.int32 and req_to_token.dim() == 2
+          and req_to_token.stride(1) == 1, "req_to_token must be an int32 [reqs, ctx] GPU tensor with dense rows")
+    _need(req_pool_indices.numel() == bs and seq_lens.numel() == bs, "req_pool_indices / seq_lens must have bs entries")
+    if out is None:
+        out = torch.empty((bs, Hq, D), dtype=torch.bfloat16, device=q.device)
+    else:
+        _dev_bf16(out, "out")
+        _need(out.shape == q.shape and out.stride(2) == 1 and out.stride(1) == D, "out must match q's layout")
+    if max_splits > 1:
+        need = decode_workspace_bytes(bs, Hq, D, max_splits)
+        if workspace is None:
+            workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
+        _need(workspace.is_cuda and workspace.is_contiguous() and workspace.numel() * workspace.element_size() >= need,
+              f"workspace must hold {need} bytes")
+    if chunk_dev is not None:
+        _dev_i32(chunk_dev, "chunk_dev")
+    elif chunk_tokens <= 0:
+        _need(max_splits == 1, "chunk_tokens is required when max_splits > 1")
+        chunk_tokens = 1 << 30  # one split covers any sequence
+    qs = q.stride(0) if bs > 1 else Hq * D
+    os_ = out.stride(0) if bs > 1 else Hq * D
+    _check(_lib.msgl_paged_decode(
+        q.data_ptr(), qs, k_cache.data_ptr(), v_cache.data_ptr(), cs,
+        req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(), seq_lens.data_ptr(),
+        out.data_ptr(), os_,
+        workspace.data_ptr() if workspace is not None else None,
+        workspace.numel() * workspace.element_size() if workspace is not None else 0,
+        bs, Hq, Hkv, D, page_size, float(scale), max_splits, int(chunk_tokens),
+        chunk_dev.data_ptr() if chunk_dev is not None else None, _stream()))
+    return out
+
+
+def pick_split(seq_lens_cpu_max: int, total_tokens: int, bs: int, max_splits: int, target_groups: int = 1024) -> int:
+    """Tokens per split for the decode kernel: a multiple of DECODE_TILE, large enough that the longest
+    sequence fits max_splits splits, small enough that about target_groups work groups are active."""
+    per_group = max(1, -(-total_tokens // max(target_groups, 1)))
+    floor_ = -(-max(seq_lens_cpu_max, 1) // max_splits)
+    chunk = max(per_group, floor_, 256)
+    return -(-chunk // DECODE_TILE) * DECODE_TILE
+
+
+# ----------------------------------------------------------------------------- extend
+def paged_extend(
+    q: torch.Tensor,
+    k_cache: torch.Tensor,
+    v_cache: torch.Tensor,
+    req_to_token: torch.Tensor,
+    req_pool_indices: torch.Tensor,
+    cu_seqlens_q: torch.Tensor,
+    prefix_lens: torch.Tensor,
+    max_seqlen_q: int,
+    scale: float,
+    page_size: int,
+    *,
+    out: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """Extend attention for packed q [sum Sq, Hq, D]; K/V of the new tokens must already be stored."""
+    _dev_bf16(q, "q")
+    _dev_i32(req_pool_indices, "req_pool_indices"), _dev_i32(cu_seqlens_q, "cu_seqlens_q"), _dev_i32(prefix_lens, "prefix_lens")
+    _need(q.dim() == 3 and q.stride(2) == 1 and q.stride(1) == q.shape[2], "q must be [T, Hq, D] with dense heads")
+    T, Hq, D = q.shape
+    bs = req_pool_indices.numel()
+    _need(cu_seqlens_q.numel() == bs + 1 and prefix_lens.numel() == bs, "cu_seqlens_q needs bs+1 and prefix_lens bs entries")
+    _need(k_cache.dim() == 3, "k_cache must be [slots, Hkv, D]")
+    Hkv = k_cache.shape[1]
+    cs = _cache_stride(k_cache, v_cache, Hkv, D)
+    _need(req_to_token.is_cuda and req_to_token.dtype == torch.int32 and req_to_token.dim() == 2
+          and req_to_token.stride(1) == 1, "req_to_token must be an int32 [reqs, ctx] GPU tensor with dense rows")
+    if out is None:
+        out = torch.empty((T, Hq, D), dtype=torch.bfloat16, device=q.device)
+    else:
+        _dev_bf16(out, "out")
+        _need(out.shape == q.shape and out.stride(2) == 1 and out.stride(1) == D, "out must match q's layout")
+    qs = q.stride(0) if T > 1 else Hq * D
+    os_ = out.stride(0) if T > 1 else Hq * D
+    _check(_lib.msgl_paged_extend(
+        q.data_ptr(), qs, k_cache.data_ptr(), v_cache.data_ptr(), cs,
+        req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(), cu_seqlens_q.data_ptr(),
+        prefix_lens.data_ptr(), out.data_ptr(), os_, bs, int(max_seqlen_q), Hq, Hkv, D, page_size, float(scale), _stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------- norms / activation / rope
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev_bf16(x, "x"), _dev_bf16(weight, "weight")
+    rows, cols, xs = _rows_view(x, "x")
+    _need(weight.numel() == cols and weight.is_contiguous(), "weight must be a dense [cols] vector")
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
+    _, ocols, os_ = _rows_view(out, "out")
+    _need(out.shape[0] == rows and ocols == cols, "out shape mismatch")
+    _check(_lib.msgl_rmsnorm(x.data_ptr(), xs, weight.data_ptr(), out.data_ptr(), os_, rows, cols, float(eps), _stream()))
+    return out
+
+
+def fused_add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> None:
+    """In place: residual += x (rounded to bf16), x = rmsnorm(unrounded sum) * weight."""
+    _dev_bf16(x, "x"), _dev_bf16(residual, "residual"), _dev_bf16(weight, "weight")
+    _need(x.dim() == 2 and x.is_contiguous() and residual.shape == x.shape and residual.is_contiguous(),
+          "x and residual must be contiguous 2-D tensors of equal shape")
+    rows, cols = x.shape
+    _need(weight.numel() == cols and weight.is_contiguous(), "weight must be a dense [cols] vector")
+    _check(_lib.msgl_fused_add_rmsnorm(x.data_ptr(), residual.data_ptr(), weight.data_ptr(), rows, cols, float(eps), _stream()))
+
+
+def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev_bf16(x, "x")
+    rows, cols2, xs = _rows_view(x, "x")
+    _need(cols2 % 2 == 0, "last dim must be even")
+    n = cols2 // 2
+    if out is None:
+        out = torch.empty((rows, n), dtype=torch.bfloat16, device=x.device)
+    _need(out.shape == (rows, n) and out.is_contiguous(), "out must be contiguous [rows, n]")
+    _check(_lib.msgl_silu_and_mul(x.data_ptr(), xs, out.data_ptr(), rows, n, _stream()))
+    return out
+
+
+def rope_neox_(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor, cos_sin_cache: torch.Tensor, head_dim: int,
+               reference_rounding: bool = True) -> None:
+    """In place on q [T, Hq*D] and k [T, Hkv*D] (row-strided views allowed)."""
+    _dev_bf16(q, "q"), _dev_bf16(k, "k"), _dev_i32(positions, "positions")
+    _need(cos_sin_cache.is_cuda and cos_sin_cache.dtype == torch.float32 and cos_sin_cache.is_contiguous()
+          and cos_sin_cache.shape[1] == head_dim, "cos_sin_cache must be a contiguous fp32 [max_pos, D] GPU tensor")
+    T, qc, qs = _rows_view(q, "q")
+    Tk, kc, ks = _rows_view(k, "k")
+    _need(T == Tk == positions.numel(), "q, k and positions disagree on the token count")
+    _need(qc % head_dim == 0 and kc % head_dim == 0, "row widths must be multiples of head_dim")
+    _check(_lib.msgl_rope_neox(positions.data_ptr(), q.data_ptr(), qs, k.data_ptr(), ks, cos_sin_cache.data_ptr(), T,
+                               qc // head_dim, kc // head_dim, head_dim, 0 if reference_rounding else 1, _stream()))
+
+
+def qknorm_rope_store_(qkv: torch.Tensor, q_weight: torch.Tensor, k_weight: torch.Tensor, eps: float,
+                       positions: torch.Tensor, cos_sin_cache: torch.Tensor, Hq: int, Hkv: int, head_dim: int,
+                       loc: Optional[torch.Tensor] = None, k_cache: Optional[torch.Tensor] = None,
+                       v_cache: Optional[torch.Tensor] = None, reference_rounding: bool = True) -> None:
+    """Per-head q/k RMSNorm + RoPE in place on qkv [T, (Hq+2Hkv)*D]; optionally scatters k, v to the pool."""
+    _dev_bf16(qkv, "qkv"), _dev_bf16(q_weight, "q_weight"), _dev_bf16(k_weight, "k_weight"), _dev_i32(positions, "positions")
+    T, cols, qs = _rows_view(qkv, "qkv")
+    _need(cols == (Hq + 2 * Hkv) * head_dim, "qkv width must be (Hq + 2*Hkv) * head_dim")
+    _need(positions.numel() == T, "positions length must equal the number of tokens")
+    _need(cos_sin_cache.is_cuda and cos_sin_cache.dtype == torch.float32 and cos_sin_cache.is_contiguous()
+          and cos_sin_cache.shape[1] == head_dim, "cos_sin_cache must be a contiguous fp32 [max_pos, D] GPU tensor")
+    _need(q_weight.numel() == head_dim and k_weight.numel() == head_dim, "norm weights must have head_dim entries")
+    if loc is not None:
+        _dev_i32(loc, "loc")
+        _need(loc.numel() == T and k_cache is not None and v_cache is not None, "loc needs T entries and both caches")
+        cs = _cache_stride(k_cache, v_cache, Hkv, head_dim)
+    else:
+        cs = Hkv * head_dim
+    _check(_lib.msgl_qknorm_rope_store(
+        qkv.data_ptr(), qs, q_weight.data_ptr(), k_weight.data_ptr(), float(eps), positions.data_ptr(),
+        cos_sin_cache.data_ptr(), loc.data_ptr() if loc is not None else None,
+        k_cache.data_ptr() if loc is not None else None, v_cache.data_ptr() if loc is not None else None,
+        cs, T, Hq, Hkv, head_dim, 0 if reference_rounding else 1, _stream()))
+
+
+def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Greedy token per row of logits [bs, vocab] (bf16 or fp32); int32 [bs]."""
+    _need(logits.is_cuda and logits.dtype in (torch.bfloat16, torch.float32), "logits must be bf16 or fp32 on the GPU")
+    bs, vocab, rs = _rows_view(logits, "logits")
+    if out is None:
+        out = torch.empty(bs, dtype=torch.int32, device=logits.device)
+    _dev_i32(out, "out")
+    _check(_lib.msgl_argmax(logits.data_ptr(), rs, logits.element_size(), out.data_ptr(), bs, vocab, _stream()))
+    return out

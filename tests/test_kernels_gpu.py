@@ -1,0 +1,337 @@
+"""Parity of every HIP kernel (called through the C ABI via mini_sglang_amd.ops) against the CPU oracle on
+seeded inputs.  Tolerances: attention outputs 2e-2 abs vs the oracle (the bound the north star puts on
+logits) and 1e-2 abs vs an fp64 evaluation; layer kernels at most one bf16 ulp apart from the oracle on a
+small fraction of elements, bit-exact for RoPE in reference-rounding mode and for integer/byte work."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+from oracle import torch_oracle as orc  # noqa: E402
+
+
+def _ops():
+    from mini_sglang_amd import ops
+    return ops
+
+
+def _synth():
+    from mini_sglang_amd.runtime import synth, workload
+    return synth, workload
+
+
+DEV = "cuda"
+
+
+def ulp_diff_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Distance in bf16 ulps (monotone integer mapping of the bit patterns)."""
+    def key(t):
+        i = t.contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
+        return torch.where(i >= 0x8000, 0x8000 - i, i)
+    return (key(a.cpu()) - key(b.cpu())).abs()
+
+
+def assert_close_fp64(out: torch.Tensor, exact: torch.Tensor, what: str):
+    """bf16 output vs an fp64 evaluation: one bf16 ulp (2^-8 relative) plus 4e-3 absolute."""
+    err = (out.double() - exact).abs()
+    bound = 4e-3 + exact.abs() * 2.0 ** -8
+    worst = (err - bound).max().item()
+    assert worst <= 0, f"{what} vs fp64: exceeds bound by {worst} (max abs err {err.max().item()})"
+
+
+def build_case(Hq, Hkv, page_size, seq_lens, seed, groups=None, prefix=None, layout="interleaved"):
+    synth, workload = _synth()
+    D = 128
+    bs = len(seq_lens)
+    pool_pages = sum(-(-s // page_size) for s in seq_lens) + 8
+    pt = workload.make_page_table(seq_lens, page_size, pool_pages, seed, groups=groups, group_prefix_lens=prefix)
+    slots = (pool_pages + 1) * page_size
+    if layout == "interleaved":
+        kv = synth.normal((slots, 2, Hkv, D), seed + 1)
+        k_cache, v_cache = kv[:, 0], kv[:, 1]
+    else:
+        k_cache, v_cache = synth.normal((slots, Hkv, D), seed + 1), synth.normal((slots, Hkv, D), seed + 2)
+    q = synth.normal((bs, Hq, D), seed + 3)
+    # more requests rows than batch entries: request b lives in row perm[b]
+    rows = bs + 3
+    perm = synth.permutation(rows, seed + 4)[:bs].to(torch.int32)
+    r2t = torch.zeros((rows, pt.req_to_token.shape[1]), dtype=torch.int32)
+    r2t[perm.long()] = pt.req_to_token
+    return dict(q=q, k_cache=k_cache, v_cache=v_cache, r2t=r2t, req_idx=perm, seq_lens=pt.seq_lens, kv_full=kv if layout == "interleaved" else None)
+
+
+def run_decode(case, page_size, **kw):
+    ops = _ops()
+    if case["kv_full"] is not None:
+        kvd = case["kv_full"].to(DEV)
+        kc, vc = kvd[:, 0], kvd[:, 1]
+    else:
+        kc, vc = case["k_cache"].to(DEV), case["v_cache"].to(DEV)
+    out = ops.paged_decode(case["q"].to(DEV), kc, vc, case["r2t"].to(DEV), case["req_idx"].to(DEV),
+                           case["seq_lens"].to(DEV), 128 ** -0.5, page_size, **kw)
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def check_decode(case, out):
+    scale = 128 ** -0.5
+    ref = orc.paged_decode_ref(case["q"], case["k_cache"], case["v_cache"], case["r2t"], case["req_idx"], case["seq_lens"], scale)
+    err = (out.float() - ref.float()).abs().max().item()
+    assert err <= 2e-2, f"vs oracle: max abs err {err}"
+    for b in range(len(case["seq_lens"])):
+        S = int(case["seq_lens"][b])
+        tok = case["r2t"][int(case["req_idx"][b]), :S]
+        exact = orc.paged_attention_fp64(case["q"][b: b + 1], case["k_cache"], case["v_cache"], tok, scale)[0]
+        assert_close_fp64(out[b], exact, f"request {b} (S={S})")
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(16, 8), (32, 8), (64, 8), (8, 1), (4, 1), (16, 4), (8, 2), (8, 8), (2, 2), (1, 1)])
+@pytest.mark.parametrize("page_size", [1, 16])
+def test_decode_heads(Hq, Hkv, page_size):
+    seq = [1, 2, 15, 16, 17, 31, 33, 100, 257, 1000]
+    case = build_case(Hq, Hkv, page_size, seq, seed=10 + Hq + Hkv)
+    check_decode(case, run_decode(case, page_size))
+
+
+@pytest.mark.parametrize("page_size", [1, 4, 16, 48, 64])
+@pytest.mark.parametrize("layout", ["interleaved", "split"])
+def test_decode_page_sizes_and_splits(page_size, layout):
+    ps = page_size
+    seq = [1, max(1, ps - 1), ps, ps + 1, 3 * ps + 5, 1023, 1024, 1025, 2500]
+    case = build_case(32, 8, ps, seq, seed=77 + ps, layout=layout)
+    base = run_decode(case, ps)
+    check_decode(case, base)
+    for max_splits, chunk in [(4, 1024), (16, 256), (64, 48), (3, 16)]:
+        out = run_decode(case, ps, max_splits=max_splits, chunk_tokens=chunk)
+        check_decode(case, out)
+    # chunk read from device memory (graph replay path), deliberately not a multiple of 16
+    cd = torch.tensor([100], dtype=torch.int32, device=DEV)
+    check_decode(case, run_decode(case, ps, max_splits=32, chunk_dev=cd))
+
+
+def test_decode_shared_prefix_rows():
+    ps = 16
+    groups = [0, 0, 0, 1, 1, 2]
+    prefix = [256, 64, 0]
+    seq = [300, 256, 1000, 64, 65, 40]
+    case = build_case(32, 8, ps, seq, seed=5, groups=groups, prefix=prefix)
+    # rows of a group really share slots
+    r2t, idx = case["r2t"], case["req_idx"].long()
+    assert torch.equal(r2t[idx[0], :256], r2t[idx[1], :256]) and torch.equal(r2t[idx[0], :256], r2t[idx[2], :256])
+    check_decode(case, run_decode(case, ps, max_splits=8, chunk_tokens=128))
+
+
+def test_decode_long_context_split():
+    case = build_case(8, 1, 64, [20000, 3], seed=9)
+    check_decode(case, run_decode(case, 64, max_splits=128, chunk_tokens=256))
+
+
+def test_decode_errors():
+    ops = _ops()
+    case = build_case(16, 8, 1, [5], seed=1)
+    with pytest.raises(ValueError):
+        ops.paged_decode(case["q"], case["k_cache"].to(DEV), case["v_cache"].to(DEV), case["r2t"].to(DEV),
+                         case["req_idx"].to(DEV), case["seq_lens"].to(DEV), 1.0, 1)  # q on the CPU
+    q96 = torch.zeros((1, 16, 96), dtype=torch.bfloat16, device=DEV)
+    kc = torch.zeros((8, 8, 96), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="head dim"):
+        ops.paged_decode(q96, kc, kc.clone(), case["r2t"].to(DEV), case["req_idx"].to(DEV), case["seq_lens"].to(DEV), 1.0, 1)
+    q3 = torch.zeros((1, 24, 128), dtype=torch.bfloat16, device=DEV)  # group of 3
+    with pytest.raises(RuntimeError, match="unsupported"):
+        ops.paged_decode(q3, case["k_cache"].to(DEV).contiguous(), case["v_cache"].to(DEV).contiguous(), case["r2t"].to(DEV),
+                         case["req_idx"].to(DEV), case["seq_lens"].to(DEV), 1.0, 1)
+
+
+# ------------------------------------------------------------------------------------------------ extend
+def build_extend_case(Hq, Hkv, page_size, prefix_lens, input_lens, seed):
+    synth, workload = _synth()
+    D = 128
+    seq = [p + n for p, n in zip(prefix_lens, input_lens)]
+    bs = len(seq)
+    pool_pages = sum(-(-s // page_size) for s in seq) + 8
+    pt = workload.make_page_table(seq, page_size, pool_pages, seed)
+    slots = (pool_pages + 1) * page_size
+    kv = synth.normal((slots, 2, Hkv, D), seed + 1)
+    q = synth.normal((sum(input_lens), Hq, D), seed + 3)
+    return dict(q=q, kv=kv, r2t=pt.req_to_token, req_idx=torch.arange(bs, dtype=torch.int32), seq_lens=pt.seq_lens,
+                prefix=torch.tensor(prefix_lens, dtype=torch.int32), inp=torch.tensor(input_lens, dtype=torch.int32))
+
+
+def run_extend(case, page_size):
+    ops = _ops()
+    kvd = case["kv"].to(DEV)
+    cu = torch.nn.functional.pad(torch.cumsum(case["inp"], 0, dtype=torch.int32), (1, 0)).to(DEV)
+    out = ops.paged_extend(case["q"].to(DEV), kvd[:, 0], kvd[:, 1], case["r2t"].to(DEV), case["req_idx"].to(DEV), cu,
+                           case["prefix"].to(DEV), int(case["inp"].max()), 128 ** -0.5, page_size)
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def check_extend(case, out):
+    scale = 128 ** -0.5
+    kc, vc = case["kv"][:, 0], case["kv"][:, 1]
+    ref = orc.paged_extend_ref(case["q"], kc, vc, case["r2t"], case["req_idx"], case["seq_lens"], case["prefix"], case["inp"], scale)
+    err = (out.float() - ref.float()).abs().max().item()
+    assert err <= 2e-2, f"vs oracle: max abs err {err}"
+    start = 0
+    for b in range(len(case["seq_lens"])):
+        S, P, n = int(case["seq_lens"][b]), int(case["prefix"][b]), int(case["inp"][b])
+        exact = orc.paged_attention_fp64(case["q"][start: start + n], kc, vc, case["r2t"][b, :S], scale,
+                                         q_positions=torch.arange(P, P + n))
+        assert_close_fp64(out[start: start + n], exact, f"request {b} (prefix {P}, new {n})")
+        start += n
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(16, 8), (32, 8), (8, 1), (4, 4)])
+@pytest.mark.parametrize("page_size", [1, 16, 64])
+def test_extend(Hq, Hkv, page_size):
+    ps = page_size
+    prefix = [0, 0, ps * 2, 0, 64 * ps // ps * (ps if ps > 1 else 1), 0]
+    prefix = [p - p % ps for p in prefix]
+    inputs = [1, 31, 33, 128, 200, 300]
+    case = build_extend_case(Hq, Hkv, ps, prefix, inputs, seed=3 + Hq + ps)
+    check_extend(case, run_extend(case, ps))
+
+
+def test_extend_long_prefix():
+    case = build_extend_case(16, 8, 16, [2048, 0], [130, 700], seed=21)
+    check_extend(case, run_extend(case, 16))
+
+
+# ------------------------------------------------------------------------------------------------ layers
+@pytest.mark.parametrize("cols", [128, 1024, 2048, 4096, 5120, 8192])
+def test_rmsnorm(cols):
+    ops = _ops()
+    synth, _ = _synth()
+    rows = 37
+    x = synth.normal((rows, cols), 1, std=2.0)
+    w = synth.normal((cols,), 2, std=0.5) + 1
+    ref = orc.rmsnorm_ref(x, w, 1e-6)
+    out = ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-6).cpu()
+    d = ulp_diff_bf16(out, ref)
+    assert d.max() <= 1 and (d > 0).float().mean() < 0.02, (d.max(), (d > 0).float().mean())
+    # strided rows (a 128-wide head slice of a wider buffer)
+    if cols == 128:
+        big = synth.normal((rows, 3 * cols), 3)
+        xs = big[:, cols: 2 * cols]
+        out = ops.rmsnorm(big.to(DEV)[:, cols: 2 * cols], w.to(DEV), 1e-6).cpu()
+        d = ulp_diff_bf16(out, orc.rmsnorm_ref(xs, w, 1e-6))
+        assert d.max() <= 1
+
+
+@pytest.mark.parametrize("cols", [1024, 4096, 5120])
+def test_fused_add_rmsnorm(cols):
+    ops = _ops()
+    synth, _ = _synth()
+    rows = 19
+    x, r = synth.normal((rows, cols), 4), synth.normal((rows, cols), 5, std=3.0)
+    w = synth.normal((cols,), 6, std=0.5) + 1
+    y_ref, r_ref = orc.rmsnorm_ref(x, w, 1e-6, residual=r)
+    xd, rd = x.to(DEV), r.to(DEV)
+    ops.fused_add_rmsnorm(xd, rd, w.to(DEV), 1e-6)
+    assert torch.equal(rd.cpu(), r_ref), "residual' = bf16(x + residual) must be bit exact"
+    d = ulp_diff_bf16(xd.cpu(), y_ref)
+    assert d.max() <= 1 and (d > 0).float().mean() < 0.02
+
+
+def test_silu_and_mul():
+    ops = _ops()
+    synth, _ = _synth()
+    for rows, n in [(5, 3072), (64, 12288), (3, 8)]:
+        x = synth.normal((rows, 2 * n), 7, std=2.0)
+        ref = orc.silu_and_mul_ref(x)
+        out = ops.silu_and_mul(x.to(DEV)).cpu()
+        d = ulp_diff_bf16(out, ref)
+        assert d.max() <= 1 and (d > 0).float().mean() < 0.01, (d.max(), (d > 0).float().mean())
+
+
+def test_rope_bit_exact_and_fp32():
+    ops = _ops()
+    synth, _ = _synth()
+    D, Hq, Hkv, T = 128, 16, 8, 50
+    cache = orc.build_cos_sin_cache(D, 40960, 1e6)
+    pos = torch.cat([torch.tensor([0, 1, 40959], dtype=torch.int32), synth.uniform_int(T - 3, 8, 0, 40960).to(torch.int32)])
+    qkv = synth.normal((T, (Hq + 2 * Hkv) * D), 9)
+    q, k = qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D]
+    q_ref, k_ref = orc.rope_ref(pos, q, k, cache, D)
+    qkv_d = qkv.to(DEV)
+    qd, kd = qkv_d[:, : Hq * D], qkv_d[:, Hq * D: (Hq + Hkv) * D]
+    ops.rope_neox_(pos.to(DEV), qd, kd, cache.to(DEV), D, reference_rounding=True)
+    assert torch.equal(qd.cpu(), q_ref) and torch.equal(kd.cpu(), k_ref), "reference-rounding RoPE must be bit exact"
+    assert torch.equal(qkv_d[:, (Hq + Hkv) * D:].cpu(), qkv[:, (Hq + Hkv) * D:]), "v part must be untouched"
+    qkv_d = qkv.to(DEV)
+    qd, kd = qkv_d[:, : Hq * D], qkv_d[:, Hq * D: (Hq + Hkv) * D]
+    ops.rope_neox_(pos.to(DEV), qd, kd, cache.to(DEV), D, reference_rounding=False)
+    q32, k32 = orc.rope_fp32_ref(pos, q, k, cache, D)
+    assert ulp_diff_bf16(qd.cpu(), q32).max() <= 1 and ulp_diff_bf16(kd.cpu(), k32).max() <= 1
+
+
+def test_store_kv_bit_exact():
+    ops = _ops()
+    synth, _ = _synth()
+    Hkv, D, T, slots = 8, 128, 40, 300
+    qkv = synth.normal((T, (16 + 2 * Hkv) * D), 11)
+    k = qkv[:, 16 * D: (16 + Hkv) * D].view(T, Hkv, D)
+    v = qkv[:, (16 + Hkv) * D:].view(T, Hkv, D)
+    loc = (synth.permutation(slots - 1, 12)[:T] + 1).to(torch.int32)
+    for layout in ("interleaved", "split"):
+        if layout == "interleaved":
+            kv = torch.zeros((slots, 2, Hkv, D), dtype=torch.bfloat16)
+            kc, vc = kv[:, 0], kv[:, 1]
+            kvd = kv.to(DEV)
+            kcd, vcd = kvd[:, 0], kvd[:, 1]
+        else:
+            kc, vc = torch.zeros((slots, Hkv, D), dtype=torch.bfloat16), torch.zeros((slots, Hkv, D), dtype=torch.bfloat16)
+            kcd, vcd = kc.to(DEV), vc.to(DEV)
+        orc.store_kv_ref(kc, vc, loc, k, v)
+        qd = qkv.to(DEV)
+        ops.store_kv(qd[:, 16 * D: (16 + Hkv) * D].view(T, Hkv, D), qd[:, (16 + Hkv) * D:].view(T, Hkv, D), loc.to(DEV), kcd, vcd)
+        assert torch.equal(kcd.cpu(), kc) and torch.equal(vcd.cpu(), vc)
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(16, 8), (32, 8), (8, 1)])
+def test_fused_qknorm_rope_store(Hq, Hkv):
+    ops = _ops()
+    synth, _ = _synth()
+    D, T, slots = 128, 33, 200
+    cache = orc.build_cos_sin_cache(D, 4096, 1e6)
+    pos = synth.uniform_int(T, 13, 0, 4096).to(torch.int32)
+    qkv = synth.normal((T, (Hq + 2 * Hkv) * D), 14, std=1.5)
+    qw, kw = synth.normal((D,), 15, std=0.3) + 1, synth.normal((D,), 16, std=0.3) + 1
+    loc = (synth.permutation(slots - 1, 17)[:T] + 1).to(torch.int32)
+    # oracle: unfused op sequence of the reference (qwen3.py:88-94 then set_kv_buffer)
+    q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    qn = orc.rmsnorm_ref(q.reshape(-1, D), qw, 1e-6).view(q.shape)
+    kn = orc.rmsnorm_ref(k.reshape(-1, D), kw, 1e-6).view(k.shape)
+    q_ref, k_ref = orc.rope_ref(pos, qn, kn, cache, D)
+    kc, vc = torch.zeros((slots, Hkv, D), dtype=torch.bfloat16), torch.zeros((slots, Hkv, D), dtype=torch.bfloat16)
+    orc.store_kv_ref(kc, vc, loc, k_ref, v)
+    kvd = torch.zeros((slots, 2, Hkv, D), dtype=torch.bfloat16, device=DEV)
+    qkv_d = qkv.to(DEV)
+    ops.qknorm_rope_store_(qkv_d, qw.to(DEV), kw.to(DEV), 1e-6, pos.to(DEV), cache.to(DEV), Hq, Hkv, D, loc=loc.to(DEV),
+                           k_cache=kvd[:, 0], v_cache=kvd[:, 1])
+    got = qkv_d.cpu()
+    dq = ulp_diff_bf16(got[:, : Hq * D], q_ref)
+    dk = ulp_diff_bf16(got[:, Hq * D: (Hq + Hkv) * D], k_ref)
+    # the norm may differ by one bf16 ulp on few elements (sum order / rsqrt); rope then mixes pairs, so allow 2
+    assert dq.max() <= 2 and dk.max() <= 2 and (dq > 0).float().mean() < 0.03, (dq.max(), dk.max(), (dq > 0).float().mean())
+    assert torch.equal(got[:, (Hq + Hkv) * D:], qkv[:, (Hq + Hkv) * D:])
+    assert torch.equal(kvd[:, 1].cpu(), vc), "v rows must be copied bit exact"
+    assert torch.equal(kvd[:, 0].cpu()[loc.long()].reshape(T, -1), got[:, Hq * D: (Hq + Hkv) * D]), "stored k = rotated k"
+
+
+def test_argmax():
+    ops = _ops()
+    synth, _ = _synth()
+    logits = synth.normal((7, 151936), 18)
+    logits[2, 100] = logits[2, 5000] = 9.0  # tie: first index wins
+    logits[3, 77] = float("nan")
+    for t in (logits, logits.float()):
+        got = ops.argmax(t.to(DEV)).cpu()
+        assert torch.equal(got, orc.argmax_ref(t)), (got, orc.argmax_ref(t))
