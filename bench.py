@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Headline benchmark: paged decode attention on MI355X, Qwen3-8B geometry, page_size 16, batch 256,
+8192-token contexts (the configuration BASELINE.json's metric is quoted on).
+
+A "step" is one decode-attention call (one transformer layer's worth: new K/V already in the pool, one
+query token per request attends to its whole paged context).  Steps cycle over several layers' pools so
+that no step can be served from the 256 MiB Infinity Cache.  Inputs are resident in HBM before the timed
+region.  value = algorithmic KV bytes (2 * Hkv * 128 * 2 B * sum of sequence lengths, no de-duplication)
+per second, summed over ranks.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): tensor parallel by KV head exactly as the
+reference shards attention (Hq/N query heads and Hkv/N kv heads per rank, identical page tables on every
+rank, no collective inside attention), so the total work is fixed: "strong" scaling.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--bs", type=int, default=256)
+    ap.add_argument("--ctx", type=int, default=8192)
+    ap.add_argument("--page-size", type=int, default=16)
+    ap.add_argument("--layers", type=int, default=4, help="distinct per-layer pools cycled through")
+    ap.add_argument("--hq", type=int, default=32)
+    ap.add_argument("--hkv", type=int, default=8)
+    ap.add_argument("--layout", default="interleaved", choices=["interleaved", "split"])
+    ap.add_argument("--max-splits", type=int, default=0, help="0 = backend default for the batch size")
+    ap.add_argument("--chunk", type=int, default=0, help="0 = backend default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    from mini_sglang_amd import ops
+    from mini_sglang_amd.attn.hip_attn_backend import splits_for_batch
+    from mini_sglang_amd.runtime import synth, workload
+
+    D = 128
+    assert args.hkv % world == 0, "tensor parallel degree must divide the kv heads"
+    Hq, Hkv = args.hq // world, args.hkv // world
+    bs, S, ps, L = args.bs, args.ctx, args.page_size, args.layers
+    pages_per_req = -(-S // ps)
+    pool_pages = bs * pages_per_req + 64
+    slots = (pool_pages + 1) * ps
+    pt = workload.make_page_table([S] * bs, ps, pool_pages, seed=3, scatter=True)
+    r2t = pt.req_to_token.to(dev)
+    seq_lens = pt.seq_lens.to(dev)
+    req_idx = torch.arange(bs, dtype=torch.int32, device=dev)
+    pools = []
+    for layer in range(L):
+        if args.layout == "interleaved":
+            kv = synth.normal((slots, 2, Hkv, D), 100 + layer * 7 + rank, device=dev)
+            pools.append((kv[:, 0], kv[:, 1]))
+        else:
+            pools.append((synth.normal((slots, Hkv, D), 100 + layer * 7 + rank, device=dev),
+                          synth.normal((slots, Hkv, D), 500 + layer * 7 + rank, device=dev)))
+    qs = [synth.normal((bs, Hq, D), 900 + layer + rank, device=dev) for layer in range(L)]
+    out = torch.empty((bs, Hq, D), dtype=torch.bfloat16, device=dev)
+    max_splits = args.max_splits or splits_for_batch(bs)
+    chunk = args.chunk or ops.pick_split(S, S * bs, bs, max_splits)
+    ws = torch.empty(max(ops.decode_workspace_bytes(bs, Hq, D, max_splits), 16), dtype=torch.uint8, device=dev)
+    scale = D ** -0.5
+
+    def step(i: int):
+        kc, vc = pools[i % L]
+        ops.paged_decode(qs[i % L], kc, vc, r2t, req_idx, seq_lens, scale, ps, out=out, workspace=ws,
+                         max_splits=max_splits, chunk_tokens=chunk)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        step(i)
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream)
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, dev_ms = float(t[0]), float(t[1])
+
+    bytes_per_step_rank = 2 * Hkv * D * 2 * S * bs
+    total_bytes = bytes_per_step_rank * world * args.steps
+    value = total_bytes / elapsed / 1e9
+    launch_ms = dev_ms / args.steps
+    achieved = bytes_per_step_rank / (launch_ms * 1e-3) / 1e9  # per GPU, device time per launch
+
+    result = {
+        "metric": "paged_decode_attention_hbm_bandwidth",
+        "value": round(value, 1),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": f"Qwen3-8B decode attention, one layer per step, batch {bs} x {S} ctx, page_size {ps}, "
+                        f"scattered pages, {L} layer pools cycled, TP={world} ({Hq} q / {Hkv} kv heads per GPU)",
+            "batch": bs, "ctx": S, "page_size": ps, "hq_per_gpu": Hq, "hkv_per_gpu": Hkv, "head_dim": D,
+            "kv_layout": args.layout, "max_splits": max_splits, "chunk_tokens": chunk, "parallelism": f"tp{world}",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": None,
+            "kernel": "paged_decode_kernel (+ split merge)",
+            "launch_ms": round(launch_ms, 4),
+            "bytes_per_launch": bytes_per_step_rank,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(pools[0], qs[0], r2t, S, ps, Hq, Hkv, D, scale, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pool, q, r2t, S, ps, Hq, Hkv, D, scale, budget_s):
+    """The oracle (the reference's per-request gather + SDPA loop, torch_attn_backend.py:114-182) timed on
+    the host cores over a bounded sample of the same workload: the first n requests of layer 0, with their
+    K/V rows copied to host memory at scattered slots."""
+    from oracle import torch_oracle as orc
+
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    kc, vc = pool
+
+    def sample(n):
+        slots_dev = r2t[:n, :S].reshape(-1).long()
+        k_h = kc[slots_dev].cpu()
+        v_h = vc[slots_dev].cpu()
+        # keep the gather scattered on the host too: place row i at a pseudo-random slot
+        from mini_sglang_amd.runtime import synth
+        perm = synth.permutation(n * S, 11)
+        k_pool = torch.empty_like(k_h)
+        v_pool = torch.empty_like(v_h)
+        k_pool[perm] = k_h
+        v_pool[perm] = v_h
+        table = perm.to(torch.int32).view(n, S)
+        return k_pool, v_pool, table
+
+    n = 2
+    k_pool, v_pool, table = sample(n)
+    qh = q[:n].cpu()
+    idx = torch.arange(n, dtype=torch.int32)
+    lens = torch.full((n,), S, dtype=torch.int32)
+    orc.paged_decode_ref(qh, k_pool, v_pool, table, idx, lens, scale)  # warm-up
+    t0 = time.perf_counter()
+    orc.paged_decode_ref(qh, k_pool, v_pool, table, idx, lens, scale)
+    per_req = (time.perf_counter() - t0) / n
+    n = int(max(2, min(q.shape[0], budget_s / max(per_req, 1e-6))))
+    k_pool, v_pool, table = sample(n)
+    qh = q[:n].cpu()
+    idx = torch.arange(n, dtype=torch.int32)
+    lens = torch.full((n,), S, dtype=torch.int32)
+    t0 = time.perf_counter()
+    orc.paged_decode_ref(qh, k_pool, v_pool, table, idx, lens, scale)
+    dt = time.perf_counter() - t0
+    gbps = 2 * Hkv * D * 2 * S * n / dt / 1e9
+    return {"value": round(gbps, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} of the batch's requests ({S} tokens each), one layer, {dt:.2f} s of host time",
+            "cpu_model": _cpu_model()}
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,8 @@
 //     small kernel merges them (requests that fit one split are written directly).
 #include "msgl_common.h"
 
+#include <type_traits>
+
 namespace msgl {
 
 constexpr int kTile = 16;    // tokens per wave iteration
@@ -59,37 +61,25 @@ __device__ __forceinline__ int split_chunk(const DecodeParams& p) {
 
 __device__ __forceinline__ uint4 ld16(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
 
-// Slots of the 4 tokens this lane's row handles in tile `tile` of the split [t0, t1).
-// PAGED16: one table read per tile (16 consecutive slots); otherwise one per token.
-// Tokens past the end map to slot 0, the pool's always-allocated dummy page.
-template <bool PAGED16>
-__device__ __forceinline__ void fetch_slots(const int32_t* r2t_row, int t0, int t1, int tile, int ntiles, int j,
-                                            int (&slot)[4]) {
-    const int tok0 = t0 + tile * kTile;
-    if (PAGED16) {
-        int base = 0;
-        if (tile < ntiles) base = r2t_row[tok0];
-        base = __builtin_amdgcn_readfirstlane(base);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) slot[i] = (tile < ntiles) ? base + i * 4 + j : 0;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int tok = tok0 + i * 4 + j;
-            slot[i] = (tok < t1) ? r2t_row[tok] : 0;
-        }
-    }
-}
+// Register ring depth (tiles of K and of V in flight per wave) by GQA group: the accumulators of 8 query
+// heads leave room for one tile, smaller groups for two.
+template <int G>
+struct RingDepth {
+    static constexpr int value = (G >= 8) ? 1 : 2;
+};
 
 template <int G, int HPB, bool PAGED16>
 __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams p) {
     constexpr int WPH = kWaves / HPB;  // waves sharing one kv head
+    constexpr int DEPTH = RingDepth<G>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lds_o = reinterpret_cast<float*>(smem);                       // [kWaves][G][128]
     float* lds_ml = lds_o + kWaves * G * kD;                             // [kWaves][G][2]
 
-    const int b = blockIdx.x / p.max_splits;
-    const int split = blockIdx.x - b * p.max_splits;
+    // split-major block order: consecutive blocks (dealt round-robin to the 8 XCDs) are different
+    // requests of the same split, so the active blocks cover every XCD whatever the split count is
+    const int split = blockIdx.x / p.bs;
+    const int b = blockIdx.x - split * p.bs;
     const int S = p.seq_lens[b];
     const int chunk = split_chunk(p);
     const int nsplit = min((S + chunk - 1) / chunk, p.max_splits);
@@ -104,6 +94,8 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
     const int c = lane & 15;   // 16-byte column chunk of the 256-byte head row
     const int h = wave / WPH;  // local kv head
     const int sub = wave - h * WPH;
+    // this wave's tiles are sub, sub + WPH, ...; "n" below counts them
+    const int my_tiles = (ntiles > sub) ? (ntiles - sub + WPH - 1) / WPH : 0;
 
     const int32_t* r2t_row = p.r2t + (int64_t)p.req_idx[b] * p.r2t_stride;
     const uint16_t* kbase = p.kc + h * kD + c * 8;
@@ -122,39 +114,53 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
         for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
     }
 
-    int tile = sub;
-    int slot_cur[4], slot_nxt[4], slot_nn[4];
-    fetch_slots<PAGED16>(r2t_row, t0, t1, tile, ntiles, j, slot_cur);
-    fetch_slots<PAGED16>(r2t_row, t0, t1, tile + WPH, ntiles, j, slot_nxt);
-    uint4 kk[4], vv[4];
+    // Table entry (entries) of own tile n, always from a valid position so that the load is
+    // unconditional: PAGED16 -> the slot of the tile's first position (wave uniform, a scalar load);
+    // otherwise lane c holds the slot of the tile's c-th token.
+    auto load_index = [&](int n) -> int {
+        int tok = t0 + (sub + n * WPH) * kTile + (PAGED16 ? 0 : c);
+        tok = min(tok, t1 - 1);
+        return r2t_row[tok];
+    };
+    // element offsets of the 4 rows this lane loads for a tile whose table entry is idx
+    auto tile_offsets = [&](int idx, int64_t (&off)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) kk[i] = ld16(kbase + (int64_t)slot_cur[i] * p.cache_stride);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) vv[i] = ld16(vbase + (int64_t)slot_cur[i] * p.cache_stride);
+        for (int i = 0; i < 4; ++i) {
+            const int slot = PAGED16 ? idx + i * 4 + j : __shfl(idx, i * 4 + j, 16);
+            off[i] = (int64_t)slot * p.cache_stride;
+        }
+    };
 
-    for (; tile < ntiles; tile += WPH) {
-        // indices two tiles ahead: older than every K/V load that follows, so consuming
-        // them one iteration later never waits on younger loads
-        fetch_slots<PAGED16>(r2t_row, t0, t1, tile + 2 * WPH, ntiles, j, slot_nn);
+    uint4 kb[DEPTH][4], vb[DEPTH][4];
+    // One tile: scores from kb[st]; refill kb[st] with own tile n + DEPTH; softmax; P.V from vb[st];
+    // refill vb[st].  idx_refill is the table entry of tile n + DEPTH (REFILL only).
+    auto tile_step = [&](auto st_tag, auto refill_tag, int n, int idx_refill) {
+        constexpr int st = decltype(st_tag)::value;
+        constexpr bool REFILL = decltype(refill_tag)::value;
+        int64_t off[4];
+        if (REFILL) tile_offsets(idx_refill, off);
 
-        const int tok0 = t0 + tile * kTile + j;
+        const int tok0 = t0 + (sub + n * WPH) * kTile + j;
         float s[G][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                float d = dot2_bf16(qv[g].x, kk[i].x, 0.f);
-                d = dot2_bf16(qv[g].y, kk[i].y, d);
-                d = dot2_bf16(qv[g].z, kk[i].z, d);
-                d = dot2_bf16(qv[g].w, kk[i].w, d);
+                float d = dot2_bf16(qv[g].x, kb[st][i].x, 0.f);
+                d = dot2_bf16(qv[g].y, kb[st][i].y, d);
+                d = dot2_bf16(qv[g].z, kb[st][i].z, d);
+                d = dot2_bf16(qv[g].w, kb[st][i].w, d);
                 d = row16_sum(d);
                 s[g][i] = (tok0 + i * 4 < t1) ? d * p.scale_log2e : -INFINITY;
             }
         }
-        // K registers are free: next tile's K goes in flight under the softmax + P.V work
+        if (REFILL) {
+            // this stage's K registers are free: refill them before the softmax work
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) kk[i] = ld16(kbase + (int64_t)slot_nxt[i] * p.cache_stride);
-
+            for (int i = 0; i < 4; ++i) kb[st][i] = ld16(kbase + off[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float pr[G][4];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint32_t w[4] = {vv[i].x, vv[i].y, vv[i].z, vv[i].w};
+            const uint32_t w[4] = {vb[st][i].x, vb[st][i].y, vb[st][i].z, vb[st][i].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float lo = bf16_lo(w[e]), hi = bf16_hi(w[e]);
@@ -185,10 +191,69 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
                 }
             }
         }
+        if (REFILL) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) vv[i] = ld16(vbase + (int64_t)slot_nxt[i] * p.cache_stride);
+            for (int i = 0; i < 4; ++i) vb[st][i] = ld16(vbase + off[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+
+    // prologue: fill the ring with own tiles 0 .. DEPTH-1 (tiles past the end re-read the last valid one)
+    int idx_next;  // table entry of the next tile to refill
+    {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) slot_nxt[i] = slot_nn[i];
+        for (int st = 0; st < DEPTH; ++st) {
+            int64_t off[4];
+            tile_offsets(load_index(st), off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kb[st][i] = ld16(kbase + off[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vb[st][i] = ld16(vbase + off[i]);
+        }
+        idx_next = load_index(DEPTH);
+    }
+
+    // steady state: every tile of the group has a refill target inside the split.  The body is
+    // branch free, so the compiler's wait counts stay exact and loads stay in flight across tiles.
+    int n0 = 0;
+    for (; n0 + 2 * DEPTH <= my_tiles; n0 += DEPTH) {
+        if constexpr (DEPTH >= 1) {
+            const int idx_r = idx_next;
+            idx_next = load_index(n0 + 0 + DEPTH + 1);
+            tile_step(std::integral_constant<int, 0>{}, T_{}, n0 + 0, idx_r);
+        }
+        if constexpr (DEPTH >= 2) {
+            const int idx_r = idx_next;
+            idx_next = load_index(n0 + 1 + DEPTH + 1);
+            tile_step(std::integral_constant<int, 1>{}, T_{}, n0 + 1, idx_r);
+        }
+    }
+    // tail: at most 2*DEPTH - 1 tiles; refill only where the target exists
+    if constexpr (DEPTH >= 1) {
+        if (n0 + 0 < my_tiles) {
+            if (n0 + 0 + DEPTH < my_tiles) {
+                const int idx_r = idx_next;
+                idx_next = load_index(n0 + 0 + DEPTH + 1);
+                tile_step(std::integral_constant<int, 0>{}, T_{}, n0 + 0, idx_r);
+            } else {
+                tile_step(std::integral_constant<int, 0>{}, F_{}, n0 + 0, 0);
+            }
+        }
+    }
+    if constexpr (DEPTH >= 2) {
+        if (n0 + 1 < my_tiles) {
+            if (n0 + 1 + DEPTH < my_tiles) {
+                const int idx_r = idx_next;
+                idx_next = load_index(n0 + 1 + DEPTH + 1);
+                tile_step(std::integral_constant<int, 1>{}, T_{}, n0 + 1, idx_r);
+            } else {
+                tile_step(std::integral_constant<int, 1>{}, F_{}, n0 + 1, 0);
+            }
+        }
+        if (n0 + 2 < my_tiles) tile_step(std::integral_constant<int, 0>{}, F_{}, n0 + 2, 0);
     }
 
     // merge the 4 DPP rows of the wave (tokens were dealt round-robin to rows)

@@ -134,12 +134,13 @@ def paged_decode(
     return out
 
 
-def pick_split(seq_lens_cpu_max: int, total_tokens: int, bs: int, max_splits: int, target_groups: int = 1024) -> int:
+def pick_split(seq_lens_cpu_max: int, total_tokens: int, bs: int, max_splits: int, target_groups: int = 512) -> int:
     """Tokens per split for the decode kernel: a multiple of DECODE_TILE, large enough that the longest
-    sequence fits max_splits splits, small enough that about target_groups work groups are active."""
+    sequence fits max_splits splits, otherwise sized so that about target_groups work groups (two per CU)
+    are active — long splits amortise a group's prologue and merge, short ones balance ragged batches."""
     per_group = max(1, -(-total_tokens // max(target_groups, 1)))
     floor_ = -(-max(seq_lens_cpu_max, 1) // max_splits)
-    chunk = max(per_group, floor_, 256)
+    chunk = max(per_group, floor_, 512)
     return -(-chunk // DECODE_TILE) * DECODE_TILE
 
 
