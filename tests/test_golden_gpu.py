@@ -1,0 +1,122 @@
+"""HIP path against the committed golden fixtures (outputs of the reference's torch-native path, see
+oracle/gen_golden.py).  Tolerances: 2e-2 abs on attention outputs and on bf16 logits (the stated parity
+bound), at most one bf16 ulp on norm / activation outputs, bit-exact for RoPE (reference rounding), for the
+fused-add residual and for every integer output (slot assignments, page tables, token streams)."""
+import pytest
+import torch
+
+import golden_cases as gc
+from oracle import gen_golden as gg
+from test_kernels_gpu import ulp_diff_bf16
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from mini_sglang_amd import ops
+    return ops
+
+
+def test_layer_ops_vs_reference_fixture():
+    ops = _ops()
+    fx = gc.load("ops.pt")
+    for rows, cols, seed in gg.OPS_CASES["rmsnorm"]:
+        x, w = gc.rmsnorm_inputs(rows, cols, seed)
+        d = ulp_diff_bf16(ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-6), fx[f"rmsnorm/{rows}x{cols}/{seed}"])
+        assert d.max() <= 1, (rows, cols, d.max())
+    for rows, cols, seed in gg.OPS_CASES["fused_add_rmsnorm"]:
+        x, r, w = gc.fused_inputs(rows, cols, seed)
+        xd, rd = x.to(DEV), r.to(DEV)
+        ops.fused_add_rmsnorm(xd, rd, w.to(DEV), 1e-6)
+        assert torch.equal(rd.cpu(), fx[f"fused_add_rmsnorm/{rows}x{cols}/{seed}/residual"])
+        assert ulp_diff_bf16(xd, fx[f"fused_add_rmsnorm/{rows}x{cols}/{seed}/y"]).max() <= 1
+    for rows, n, seed in gg.OPS_CASES["silu_and_mul"]:
+        d = ulp_diff_bf16(ops.silu_and_mul(gc.silu_inputs(rows, n, seed).to(DEV)), fx[f"silu_and_mul/{rows}x{n}/{seed}"])
+        assert d.max() <= 1
+    from mini_sglang_amd.layers.rotary_embedding import build_cos_sin_cache
+    for T, Hq, Hkv, D, seed in gg.OPS_CASES["rope"]:
+        pos, q, k = gc.rope_inputs(T, Hq, Hkv, D, seed)
+        cache = build_cos_sin_cache(D, 40960, 1e6)
+        key = f"rope/{T}x{Hq}x{Hkv}x{D}/{seed}"
+        assert torch.equal(cache[[0, 1, 40959]], fx[key + "/cache_rows"])
+        qd, kd = q.to(DEV), k.to(DEV)
+        ops.rope_neox_(pos.to(DEV), qd, kd, cache.to(DEV), D, reference_rounding=True)
+        assert torch.equal(qd.cpu(), fx[key + "/q"]) and torch.equal(kd.cpu(), fx[key + "/k"])
+
+
+def test_attention_vs_reference_fixture():
+    ops = _ops()
+    fx = gc.load("attention.pt")
+    scale = 128 ** -0.5
+    for ci, case in enumerate(gg.ATTN_DECODE_CASES):
+        c = gc.decode_inputs(case)
+        kc, vc = c["kc"].to(DEV), c["vc"].to(DEV)
+        ops.store_kv(c["k_new"].to(DEV), c["v_new"].to(DEV), c["loc"].to(DEV), kc, vc)
+        for max_splits, chunk in [(1, 0), (8, 128)]:
+            out = ops.paged_decode(c["q"].to(DEV).view(-1, c["Hq"], 128), kc, vc, c["pt"].req_to_token.to(DEV), c["req_idx"].to(DEV),
+                                   c["pt"].seq_lens.to(DEV), scale, c["ps"], max_splits=max_splits, chunk_tokens=chunk)
+            err = (out.cpu().float().reshape(len(case[3]), -1) - fx[f"decode/{ci}"].float()).abs().max().item()
+            assert err <= 2e-2, f"decode case {ci} splits {max_splits}: {err}"
+    for ci, case in enumerate(gg.ATTN_EXTEND_CASES):
+        c = gc.extend_inputs(case)
+        kc, vc = c["kc"].to(DEV), c["vc"].to(DEV)
+        ops.store_kv(c["k_new"].to(DEV), c["v_new"].to(DEV), c["loc"].to(DEV), kc, vc)
+        cu = torch.nn.functional.pad(torch.cumsum(c["inp"], 0, dtype=torch.int32), (1, 0)).to(DEV)
+        out = ops.paged_extend(c["q"].to(DEV).view(-1, c["Hq"], 128), kc, vc, c["pt"].req_to_token.to(DEV), c["req_idx"].to(DEV), cu,
+                               c["prefix"].to(DEV), int(c["inp"].max()), scale, c["ps"])
+        got = out.cpu().float().reshape(out.shape[0], -1)[:, ::gg.EXTEND_COL_STRIDE]
+        err = (got - fx[f"extend/{ci}"].float()).abs().max().item()
+        assert err <= 2e-2, f"extend case {ci}: {err}"
+
+
+def _check_e2e(got, fx, need_identical_stream):
+    # integer outputs: slot assignment and page tables never depend on the sampled tokens
+    for key in ("out_cache_loc_first", "out_cache_loc_decode", "req_to_token_rows"):
+        assert torch.equal(got[key], fx[key]), key
+    same = (got["tokens"] == fx["tokens"])
+    if need_identical_stream:
+        assert bool(same.all()), f"greedy streams differ at {(~same).nonzero()[:4].tolist()}"
+        steps = fx["tokens"].shape[1]
+    else:
+        # random head: compare up to the first step where the reference's own top-2 margin is below 4 bf16 ulps
+        weak = (fx["margins"] < 0.125).any(dim=1).nonzero()
+        steps = int(weak[0]) if weak.numel() else fx["tokens"].shape[1]
+        assert bool(same[:, :steps].all())
+        steps += 1  # the logits of the first weak step were still computed from identical inputs
+    d_top = (got["top1_logits"][:steps] - fx["top1_logits"][:steps]).abs().max().item()
+    d_sl = (got["logits_slices"][:steps].float() - fx["logits_slices"][:steps].float()).abs().max().item()
+    assert d_top <= 2e-2 and d_sl <= 2e-2, (d_top, d_sl)
+
+
+@pytest.mark.parametrize("name,strict", [("tiny_ps1", False), ("tiny_ps16", True), ("qwen3_0.6b_ps1", True)])
+def test_e2e_greedy_stream_vs_reference_fixture(name, strict):
+    """BASELINE config 1 ("qwen3_0.6b_ps1": Qwen3-0.6B shape, page_size 1, 256 greedy tokens) and two small
+    cases: HIP attention backend + HIP layers reproduce the reference's token stream, logits within 2e-2."""
+    fx = gc.load(f"e2e_{name}.pt")
+    got = gc.run_e2e(name, DEV, kv_layout="interleaved")
+    _check_e2e(got, fx, strict)
+
+
+@pytest.mark.parametrize("name", ["tiny_ps16", "qwen3_0.6b_ps1"])
+def test_e2e_graph_replay_matches_eager(name):
+    """Decode steps replayed from captured hipGraphs (padded batch sizes included: bs 2 and 3 run in the
+    graphs of 2 and 4) give the same stream and logits as the fixture."""
+    fx = gc.load(f"e2e_{name}.pt")
+    steps = 48
+    got = gc.run_e2e(name, DEV, new_tokens=steps, use_graph=True)
+    assert got["graph_steps"] == steps - 1
+    assert torch.equal(got["tokens"], fx["tokens"][:, :steps])
+    assert (got["top1_logits"] - fx["top1_logits"][:steps]).abs().max().item() <= 2e-2
+    assert torch.equal(got["out_cache_loc_decode"], fx["out_cache_loc_decode"][: steps - 1])
+
+
+def test_e2e_hip_vs_oracle_on_same_device():
+    """Same weights, same GEMM library, same page tables; only the hot path differs (HIP kernels vs the torch
+    restatement executed on the GPU): identical streams and logits within 2e-2."""
+    from oracle import modules_oracle as mo
+    hip = gc.run_e2e("tiny_ps16", DEV)
+    ref = gc.run_e2e("tiny_ps16", DEV, layers=mo, backend_factory=mo.OracleAttnBackend)
+    assert torch.equal(hip["tokens"], ref["tokens"])
+    assert (hip["logits_slices"].float() - ref["logits_slices"].float()).abs().max().item() <= 2e-2
+    assert torch.equal(hip["req_to_token_rows"], ref["req_to_token_rows"])
