@@ -36,9 +36,10 @@ class HipAttnMetadata:
 
 
 def splits_for_batch(bs: int) -> int:
-    """Upper bound on splits per request: enough work groups (bs * splits ~ 2048) to fill 256 CUs a few
-    times over at small batch, 1 at large batch where requests alone fill the chip."""
-    return max(1, min(512, -(-2048 // max(bs, 1))))
+    """Upper bound on splits per request (the launch has bs * splits work groups, most of which exit at once
+    for short requests): up to 8192 groups in all, so a 32k-token request in a batch of 256 can still be cut
+    into 1k-token pieces, and a single 128k-token request into 512."""
+    return max(1, min(512, -(-8192 // max(bs, 1))))
 
 
 class HipAttnBackend(AttentionBackend):

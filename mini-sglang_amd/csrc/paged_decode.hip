@@ -61,11 +61,10 @@ __device__ __forceinline__ int split_chunk(const DecodeParams& p) {
 
 __device__ __forceinline__ uint4 ld16(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
 
-// Register ring depth (tiles of K and of V in flight per wave) by GQA group: the accumulators of 8 query
-// heads leave room for one tile, smaller groups for two.
+// Register ring depth: tiles of K and of V in flight per wave.
 template <int G>
 struct RingDepth {
-    static constexpr int value = (G >= 8) ? 1 : 2;
+    static constexpr int value = (G >= 8) ? 1 : 2;  // 64 accumulators at G = 8 leave room for one tile
 };
 
 template <int G, int HPB, bool PAGED16>
@@ -141,55 +140,65 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
         if (REFILL) tile_offsets(idx_refill, off);
 
         const int tok0 = t0 + (sub + n * WPH) * kTile + j;
-        float s[G][4];
+        // query heads are taken GS at a time (scores -> softmax -> P.V per group) so that only GS * 4
+        // scores and probabilities are live beside the G * 8 accumulators
+        constexpr int GS = G < 4 ? G : 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float d = dot2_bf16(qv[g].x, kb[st][i].x, 0.f);
-                d = dot2_bf16(qv[g].y, kb[st][i].y, d);
-                d = dot2_bf16(qv[g].z, kb[st][i].z, d);
-                d = dot2_bf16(qv[g].w, kb[st][i].w, d);
-                d = row16_sum(d);
-                s[g][i] = (tok0 + i * 4 < t1) ? d * p.scale_log2e : -INFINITY;
-            }
-        }
-        if (REFILL) {
-            // this stage's K registers are free: refill them before the softmax work
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) kb[st][i] = ld16(kbase + off[i]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        float pr[G][4];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float mt = fmaxf(fmaxf(s[g][0], s[g][1]), fmaxf(s[g][2], s[g][3]));
-            const float mn = fmaxf(m[g], mt);
-            const float alpha = fast_exp2(m[g] - mn);
-            float ps = 0.f;
+        for (int g0 = 0; g0 < G; g0 += GS) {
+            float s[GS][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                pr[g][i] = fast_exp2(s[g][i] - mn);
-                ps += pr[g][i];
-            }
-            l[g] = l[g] * alpha + ps;
-            m[g] = mn;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[g][e] *= alpha;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t w[4] = {vb[st][i].x, vb[st][i].y, vb[st][i].z, vb[st][i].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float lo = bf16_lo(w[e]), hi = bf16_hi(w[e]);
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    acc[g][2 * e] = fmaf(pr[g][i], lo, acc[g][2 * e]);
-                    acc[g][2 * e + 1] = fmaf(pr[g][i], hi, acc[g][2 * e + 1]);
+                for (int gg = 0; gg < GS; ++gg) {
+                    const int g = g0 + gg;
+                    float d = dot2_bf16(qv[g].x, kb[st][i].x, 0.f);
+                    d = dot2_bf16(qv[g].y, kb[st][i].y, d);
+                    d = dot2_bf16(qv[g].z, kb[st][i].z, d);
+                    d = dot2_bf16(qv[g].w, kb[st][i].w, d);
+                    d = row16_sum(d);
+                    s[gg][i] = (tok0 + i * 4 < t1) ? d * p.scale_log2e : -INFINITY;
                 }
             }
+            if (REFILL && g0 + GS >= G) {
+                // this stage's K registers are free: refill them before the remaining softmax / P.V work
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) kb[st][i] = ld16(kbase + off[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float pr[GS][4];
+#pragma unroll
+            for (int gg = 0; gg < GS; ++gg) {
+                const int g = g0 + gg;
+                const float mt = fmaxf(fmaxf(s[gg][0], s[gg][1]), fmaxf(s[gg][2], s[gg][3]));
+                const float mn = fmaxf(m[g], mt);
+                const float alpha = fast_exp2(m[g] - mn);
+                float ps = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pr[gg][i] = fast_exp2(s[gg][i] - mn);
+                    ps += pr[gg][i];
+                }
+                l[g] = l[g] * alpha + ps;
+                m[g] = mn;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[g][e] *= alpha;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t w[4] = {vb[st][i].x, vb[st][i].y, vb[st][i].z, vb[st][i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = bf16_lo(w[e]), hi = bf16_hi(w[e]);
+#pragma unroll
+                    for (int gg = 0; gg < GS; ++gg) {
+                        const int g = g0 + gg;
+                        acc[g][2 * e] = fmaf(pr[gg][i], lo, acc[g][2 * e]);
+                        acc[g][2 * e + 1] = fmaf(pr[gg][i], hi, acc[g][2 * e + 1]);
+                    }
+                }
+            }
+            if (g0 + GS < G) __builtin_amdgcn_sched_barrier(0);  // keep the groups' live ranges apart
         }
         if (REFILL) {
             __builtin_amdgcn_sched_barrier(0);
@@ -320,30 +329,61 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
     }
 }
 
-// Merge the split-K partials of one (request, query head); 64 lanes x 2 columns.
-__global__ __launch_bounds__(64) void paged_decode_merge_kernel(DecodeParams p) {
+// Merge the split-K partials of one (request, query head).  256 threads: the 4 waves take every 4th
+// split, lane l owns output columns 2l and 2l+1; split weights are formed once (all threads, in
+// parallel over splits) and kept in LDS, so the per-split work is two independent loads and two FMAs.
+constexpr int kMergeMaxSplits = 4096;
+__global__ __launch_bounds__(256) void paged_decode_merge_kernel(DecodeParams p) {
+    __shared__ float red[4];
+    __shared__ float wts[kMergeMaxSplits];
+    __shared__ float part[4][kD];
     const int b = blockIdx.x / p.Hq;
     const int hq = blockIdx.x - b * p.Hq;
     const int S = p.seq_lens[b];
     const int chunk = split_chunk(p);
     const int nsplit = min((S + chunk - 1) / chunk, p.max_splits);
     if (nsplit <= 1) return;  // written directly by the main kernel
-    const int d = threadIdx.x * 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row0 = ((int64_t)b * p.max_splits) * p.Hq + hq;
+    // running max over splits
     float M = kNegBig;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, p.ws_ml[(row0 + (int64_t)s * p.Hq) * 2]);
-    float L = 0.f, o0 = 0.f, o1 = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const int64_t row = row0 + (int64_t)s * p.Hq;
-        const float2 ml = *reinterpret_cast<const float2*>(p.ws_ml + row * 2);
+    for (int s = tid; s < nsplit; s += 256) M = fmaxf(M, p.ws_ml[(row0 + (int64_t)s * p.Hq) * 2]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off));
+    if (lane == 0) red[wave] = M;
+    __syncthreads();
+    M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    // split weights and the normaliser
+    float L = 0.f;
+    for (int s = tid; s < nsplit; s += 256) {
+        const float2 ml = *reinterpret_cast<const float2*>(p.ws_ml + (row0 + (int64_t)s * p.Hq) * 2);
         const float f = fast_exp2(ml.x - M);
+        wts[s] = f;
         L += f * ml.y;
-        const float2 o = *reinterpret_cast<const float2*>(p.ws_o + row * kD + d);
-        o0 += f * o.x;
-        o1 += f * o.y;
     }
-    const float inv = 1.0f / L;
-    *reinterpret_cast<uint32_t*>(p.out + (int64_t)b * p.out_stride + hq * kD + d) = pack_bf16(o0 * inv, o1 * inv);
+    L = wave_sum(L);
+    if (lane == 0) red[wave] = L;
+    __syncthreads();
+    L = red[0] + red[1] + red[2] + red[3];
+    // weighted sum of the partial outputs
+    const int d = lane * 2;
+    float o0 = 0.f, o1 = 0.f;
+    for (int s = wave; s < nsplit; s += 4) {
+        const float2 o = *reinterpret_cast<const float2*>(p.ws_o + (row0 + (int64_t)s * p.Hq) * kD + d);
+        const float f = wts[s];
+        o0 = fmaf(f, o.x, o0);
+        o1 = fmaf(f, o.y, o1);
+    }
+    part[wave][d] = o0;
+    part[wave][d + 1] = o1;
+    __syncthreads();
+    if (wave == 0) {
+        o0 = part[0][d] + part[1][d] + part[2][d] + part[3][d];
+        o1 = part[0][d + 1] + part[1][d + 1] + part[2][d + 1] + part[3][d + 1];
+        const float inv = 1.0f / L;
+        *reinterpret_cast<uint32_t*>(p.out + (int64_t)b * p.out_stride + hq * kD + d) = pack_bf16(o0 * inv, o1 * inv);
+    }
 }
 
 template <int G, int HPB>
@@ -357,7 +397,7 @@ static int launch_decode(const DecodeParams& p, int page_size, hipStream_t strea
     int rc = check_launch("paged_decode_kernel");
     if (rc) return rc;
     if (p.max_splits > 1) {
-        hipLaunchKernelGGL(paged_decode_merge_kernel, dim3(p.bs * p.Hq), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(paged_decode_merge_kernel, dim3(p.bs * p.Hq), dim3(256), 0, stream, p);
         rc = check_launch("paged_decode_merge_kernel");
     }
     return rc;

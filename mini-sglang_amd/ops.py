@@ -134,11 +134,14 @@ def paged_decode(
     return out
 
 
-def pick_split(seq_lens_cpu_max: int, total_tokens: int, bs: int, max_splits: int, target_groups: int = 512) -> int:
-    """Tokens per split for the decode kernel: a multiple of DECODE_TILE, large enough that the longest
-    sequence fits max_splits splits, otherwise sized so that about target_groups work groups (two per CU)
-    are active — long splits amortise a group's prologue and merge, short ones balance ragged batches."""
-    per_group = max(1, -(-total_tokens // max(target_groups, 1)))
+def pick_split(seq_lens_cpu_max: int, total_tokens: int, bs: int, max_splits: int) -> int:
+    """Tokens per split for the decode kernel: a multiple of DECODE_TILE such that the longest sequence fits
+    max_splits splits.  Uniform batches get about two work groups per CU (long splits amortise a group's
+    prologue and merge); ragged batches get about eight, so that short requests and the tails of long ones
+    even out over the 256 CUs."""
+    ragged = seq_lens_cpu_max * bs > 1.25 * total_tokens
+    target_groups = 2048 if ragged else 512
+    per_group = max(1, -(-total_tokens // target_groups))
     floor_ = -(-max(seq_lens_cpu_max, 1) // max_splits)
     chunk = max(per_group, floor_, 512)
     return -(-chunk // DECODE_TILE) * DECODE_TILE
