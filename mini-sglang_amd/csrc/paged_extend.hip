@@ -43,19 +43,63 @@ struct ExtendParams {
     uint16_t* out;
     int64_t out_stride;
     int tiles_per_req;
+    int bs;
     int group;  // query heads per kv head
     float scale_log2e;
 };
 
 __device__ __forceinline__ bf16x8_t as_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
 
+// Staging of one 64-key tile: thread owns 16-byte chunk c16 of keys skey, skey+16, skey+32, skey+48.
+// Positions past the last visible key re-read that key (always a valid slot), so the loads are
+// unconditional; the causal mask discards those columns.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+struct StageRegs {
+    u32x4_t k0, k1, k2, k3, v0, v1, v2, v3;
+};
+
+__device__ __forceinline__ StageRegs stage_load(const uint16_t* kcol, const uint16_t* vcol, int64_t cache_stride,
+                                                const int32_t* r2t_row, int kt, int skey, int kv_len) {
+    const int base = kt * kBN + skey;
+    const int64_t o0 = (int64_t)r2t_row[min(base, kv_len - 1)] * cache_stride;
+    const int64_t o1 = (int64_t)r2t_row[min(base + 16, kv_len - 1)] * cache_stride;
+    const int64_t o2 = (int64_t)r2t_row[min(base + 32, kv_len - 1)] * cache_stride;
+    const int64_t o3 = (int64_t)r2t_row[min(base + 48, kv_len - 1)] * cache_stride;
+    StageRegs r;
+    r.k0 = *reinterpret_cast<const u32x4_t*>(kcol + o0);
+    r.v0 = *reinterpret_cast<const u32x4_t*>(vcol + o0);
+    r.k1 = *reinterpret_cast<const u32x4_t*>(kcol + o1);
+    r.v1 = *reinterpret_cast<const u32x4_t*>(vcol + o1);
+    r.k2 = *reinterpret_cast<const u32x4_t*>(kcol + o2);
+    r.v2 = *reinterpret_cast<const u32x4_t*>(vcol + o2);
+    r.k3 = *reinterpret_cast<const u32x4_t*>(kcol + o3);
+    r.v3 = *reinterpret_cast<const u32x4_t*>(vcol + o3);
+    return r;
+}
+
+__device__ __forceinline__ void stage_write(char* lds_k, char* lds_v, int skey, int c16, const StageRegs& r) {
+    // keys skey + 16 i: (key & 15) == (skey & 15) for every i
+    char* kd = lds_k + skey * kKRow + ((c16 ^ (skey & 15)) << 4);
+    char* vd = lds_v + skey * kVRow + (c16 << 4);
+    *reinterpret_cast<u32x4_t*>(kd) = r.k0;
+    *reinterpret_cast<u32x4_t*>(kd + 16 * kKRow) = r.k1;
+    *reinterpret_cast<u32x4_t*>(kd + 32 * kKRow) = r.k2;
+    *reinterpret_cast<u32x4_t*>(kd + 48 * kKRow) = r.k3;
+    *reinterpret_cast<u32x4_t*>(vd) = r.v0;
+    *reinterpret_cast<u32x4_t*>(vd + 16 * kVRow) = r.v1;
+    *reinterpret_cast<u32x4_t*>(vd + 32 * kVRow) = r.v2;
+    *reinterpret_cast<u32x4_t*>(vd + 48 * kVRow) = r.v3;
+}
+
 __global__ __launch_bounds__(256) void paged_extend_kernel(ExtendParams p) {
     __shared__ __attribute__((aligned(16))) char lds[kBN * kKRow + kBN * kVRow];
     char* lds_k = lds;
     char* lds_v = lds + kBN * kKRow;
 
-    const int b = blockIdx.x / p.tiles_per_req;
-    const int qt = blockIdx.x - b * p.tiles_per_req;
+    // x = tile-major over requests, last (heaviest under the causal mask) query tile first, so the long
+    // blocks start early and the short ones fill the tail
+    const int b = blockIdx.x % p.bs;
+    const int qt = p.tiles_per_req - 1 - blockIdx.x / p.bs;
     const int hq = blockIdx.y;
     const int hk = hq / p.group;
     const int q0 = p.cu_q[b];
@@ -95,32 +139,14 @@ __global__ __launch_bounds__(256) void paged_extend_kernel(ExtendParams p) {
     // staging: thread owns 16-byte chunk c16 of keys skey, skey+16, skey+32, skey+48 of a tile
     const int c16 = tid & 15;
     const int skey = tid >> 4;
-    uint4 kst[4], vst[4];
-    auto stage_load = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int tok = kt * kBN + skey + i * 16;
-            const int slot = (tok < kv_len) ? r2t_row[tok] : 0;  // slot 0: the pool's dummy page
-            const int64_t off = (int64_t)slot * p.cache_stride + hk * kHD + c16 * 8;
-            kst[i] = *reinterpret_cast<const uint4*>(p.kc + off);
-            vst[i] = *reinterpret_cast<const uint4*>(p.vc + off);
-        }
-    };
-    auto stage_write = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int key = skey + i * 16;
-            *reinterpret_cast<uint4*>(lds_k + key * kKRow + ((c16 ^ (key & 15)) << 4)) = kst[i];
-            *reinterpret_cast<uint4*>(lds_v + key * kVRow + (c16 << 4)) = vst[i];
-        }
-    };
-
-    stage_load(0);
+    const uint16_t* kcol = p.kc + hk * kHD + c16 * 8;
+    const uint16_t* vcol = p.vc + hk * kHD + c16 * 8;
+    StageRegs stg = stage_load(kcol, vcol, p.cache_stride, r2t_row, 0, skey, kv_len);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();  // every wave is done reading the previous tile
-        stage_write();
+        stage_write(lds_k, lds_v, skey, c16, stg);
         __syncthreads();
-        if (kt + 1 < nkt) stage_load(kt + 1);
+        stg = stage_load(kcol, vcol, p.cache_stride, r2t_row, min(kt + 1, nkt - 1), skey, kv_len);  // last tile: harmless re-read
 
         const int k0 = kt * kBN;
 #pragma unroll
@@ -161,10 +187,12 @@ __global__ __launch_bounds__(256) void paged_extend_kernel(ExtendParams p) {
                 ps += st[r];
             }
             l = l * alpha + ps;  // per-lane partial sum; halves are added after the loop
+            if (!__all(alpha == 1.0f)) {  // the running max settles after a few tiles: usually nothing to rescale
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
+                for (int d = 0; d < 4; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
             // P^T fragments: registers 8s..8s+7 are k-step s; element j is key 16s + 8(j>>2) + 4h + (j&3)
             uint4 pf[2];
 #pragma unroll
@@ -244,6 +272,7 @@ extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_
     p.out = static_cast<uint16_t*>(out);
     p.out_stride = out_stride;
     p.tiles_per_req = (max_seqlen_q + kBM - 1) / kBM;
+    p.bs = bs;
     p.group = Hq / Hkv;
     p.scale_log2e = scale * 1.4426950408889634f;
     const int64_t gx = (int64_t)bs * p.tiles_per_req;
