@@ -243,24 +243,47 @@ __device__ __forceinline__ float to_f32<uint16_t>(uint16_t v) { return __builtin
 template <>
 __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 
+// total order used by torch.argmax: NaN is the largest value, ties go to the lower index
+__device__ __forceinline__ bool argmax_better(float v, int i, float bv, int bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn != bn) return vn;
+    if (vn) return i < bi;
+    return v > bv || (v == bv && i < bi);
+}
+
+// One 1024-thread block per row; 16 bytes per thread per step when the row is 16-byte aligned.
 template <typename T>
-__global__ __launch_bounds__(256) void argmax_kernel(const T* logits, int64_t row_stride, int32_t* out, int vocab) {
-    __shared__ float bv[4];
-    __shared__ int bi[4];
+__global__ __launch_bounds__(1024) void argmax_kernel(const T* logits, int64_t row_stride, int32_t* out, int vocab, int vec_ok) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    constexpr int VEC = 16 / sizeof(T);
     const T* row = logits + (int64_t)blockIdx.x * row_stride;
     float best = -INFINITY;
     int besti = 0x7fffffff;
-    // total order used by torch.argmax: NaN is the largest value, ties go to the lower index
-    auto better = [](float v, int i, float bvv, int bii) {
-        const bool vn = v != v, bn = bvv != bvv;
-        if (vn != bn) return vn;
-        if (vn) return i < bii;
-        return v > bvv || (v == bvv && i < bii);
-    };
-    for (int i = threadIdx.x; i < vocab; i += 256) {
-        const float v = to_f32<T>(row[i]);
-        if (better(v, i, best, besti)) {
-            best = v;
+    int done = 0;
+    if (vec_ok) {
+        const int nvec = vocab / VEC;
+        for (int v = threadIdx.x; v < nvec; v += 1024) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(row + (int64_t)v * VEC);
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float x;
+                if (sizeof(T) == 2) x = (e & 1) ? bf16_hi(w[e >> 1]) : bf16_lo(w[e >> 1]);
+                else x = __builtin_bit_cast(float, w[e]);
+                const int i = v * VEC + e;
+                if (argmax_better(x, i, best, besti)) {
+                    best = x;
+                    besti = i;
+                }
+            }
+        }
+        done = nvec * VEC;
+    }
+    for (int i = done + threadIdx.x; i < vocab; i += 1024) {
+        const float x = to_f32<T>(row[i]);
+        if (argmax_better(x, i, best, besti)) {
+            best = x;
             besti = i;
         }
     }
@@ -268,7 +291,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const T* logits, int64_t ro
     for (int off = 1; off < 64; off <<= 1) {
         const float ov = __shfl_xor(best, off);
         const int oi = __shfl_xor(besti, off);
-        if (better(ov, oi, best, besti)) {
+        if (argmax_better(ov, oi, best, besti)) {
             best = ov;
             besti = oi;
         }
@@ -279,8 +302,8 @@ __global__ __launch_bounds__(256) void argmax_kernel(const T* logits, int64_t ro
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (better(bv[w], bi[w], best, besti)) {
+        for (int w = 1; w < 16; ++w)
+            if (argmax_better(bv[w], bi[w], best, besti)) {
                 best = bv[w];
                 besti = bi[w];
             }
@@ -434,11 +457,12 @@ extern "C" int msgl_argmax(const void* logits, int64_t row_stride, int elem_byte
     MSGL_REQUIRE(bs > 0 && vocab > 0 && logits && out, "msgl_argmax: bs=%d vocab=%d or null pointer", bs, vocab);
     MSGL_REQUIRE(elem_bytes == 2 || elem_bytes == 4, "msgl_argmax: elem_bytes=%d (2 = bf16, 4 = fp32)", elem_bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const int vec_ok = aligned16(logits) && (row_stride * elem_bytes) % 16 == 0;
     if (elem_bytes == 2)
-        hipLaunchKernelGGL((argmax_kernel<uint16_t>), dim3(bs), dim3(256), 0, st, static_cast<const uint16_t*>(logits),
-                           row_stride, out, vocab);
+        hipLaunchKernelGGL((argmax_kernel<uint16_t>), dim3(bs), dim3(1024), 0, st, static_cast<const uint16_t*>(logits),
+                           row_stride, out, vocab, vec_ok);
     else
-        hipLaunchKernelGGL((argmax_kernel<float>), dim3(bs), dim3(256), 0, st, static_cast<const float*>(logits), row_stride,
-                           out, vocab);
+        hipLaunchKernelGGL((argmax_kernel<float>), dim3(bs), dim3(1024), 0, st, static_cast<const float*>(logits), row_stride,
+                           out, vocab, vec_ok);
     return check_launch("argmax");
 }
