@@ -80,6 +80,11 @@ int msgl_store_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stri
  * chunk_tokens; must be a positive multiple of 16 with
  * ceil(max seq_len / chunk) <= max_splits) and the rest exit at once, so the launch
  * shape never depends on the sequence lengths (hipGraph replay).
+ * Cache policy: kv_stream = 0 reads every K/V row with ordinary (cached) loads.  kv_stream = 1
+ * reads with the non-temporal hint, except positions below reuse_lens[b] (int32 [bs], may be
+ * NULL = no such positions): those are the prefix slots that the radix cache shares between
+ * requests (batch_info.py:184-186, 215-219) and are kept cacheable so that the other requests'
+ * re-reads hit L2 / the Infinity Cache.  The policy never changes results.
  * workspace: >= msgl_paged_decode_workspace_bytes(...) bytes of device memory,
  *   16-byte aligned; contents are scratch.
  * Supported: D == 128; Hq/Hkv in {1, 2, 4, 8}; Hkv in {1, 2, 4, 8}.
@@ -94,6 +99,7 @@ int msgl_paged_decode(const void* q, int64_t q_stride,
                       void* workspace, size_t workspace_bytes,
                       int bs, int Hq, int Hkv, int D, int page_size, float scale,
                       int max_splits, int chunk_tokens, const int32_t* chunk_dev,
+                      int kv_stream, const int32_t* reuse_lens,
                       void* stream);
 
 /* ---------------------------------------------------------------------------

@@ -30,6 +30,7 @@ class HipAttnMetadata:
     max_splits: int = 1
     chunk_tokens: int = 0
     chunk_dev: Optional[torch.Tensor] = None
+    reuse_lens: Optional[torch.Tensor] = None  # per request: leading positions shared with other requests
     # extend
     cu_seqlens_q: Optional[torch.Tensor] = None
     max_seqlen_q: int = 0
@@ -52,6 +53,9 @@ class HipAttnBackend(AttentionBackend):
         self.page_size = model_runner.page_size
         self.max_context_len = model_runner.model_config.max_context_len
         self._workspace: Optional[torch.Tensor] = None
+        # K/V rows are read once per step: stream them past the caches (non-temporal), keeping only the
+        # prefix positions that several requests share cacheable
+        self.kv_stream = True
         self.decode_graph_vars: Optional[dict] = None
         self.decode_graph_metadata: Dict[int, HipAttnMetadata] = {}
 
@@ -77,6 +81,9 @@ class HipAttnBackend(AttentionBackend):
         if batch.forward_mode.is_decode():
             md.max_splits = splits_for_batch(bs)
             md.chunk_tokens = self._decode_split(batch.seq_lens_cpu, bs, md.max_splits)
+            # eager launches know the longest sequence: launch only the splits that can be active
+            md.max_splits = max(1, min(md.max_splits, -(-int(batch.seq_lens_cpu.max()) // md.chunk_tokens)))
+            md.reuse_lens = getattr(batch, "shared_prefix_lens", None)
         else:
             md.max_seqlen_q = int(batch.input_seq_lens_max)
             md.cu_seqlens_q = torch.nn.functional.pad(torch.cumsum(batch.input_seq_lens, dim=0, dtype=torch.int32), (1, 0))
@@ -104,14 +111,16 @@ class HipAttnBackend(AttentionBackend):
             _as_heads(q, layer.num_heads, layer.head_dim), k_cache, v_cache, self.req_to_token_pool.req_to_token,
             batch.req_pool_indices, batch.seq_lens, layer.scale, self.page_size,
             workspace=self._workspace_for(bs, layer.num_heads, layer.head_dim, md.max_splits),
-            max_splits=md.max_splits, chunk_tokens=md.chunk_tokens, chunk_dev=md.chunk_dev)
+            max_splits=md.max_splits, chunk_tokens=md.chunk_tokens, chunk_dev=md.chunk_dev,
+            kv_stream=self.kv_stream, reuse_lens=md.reuse_lens)
         return o.view(bs, layer.num_heads * layer.head_dim)
 
     # ------------------------------------------------------------------ graph hooks
     def init_cuda_graph_state(self, max_bs: int, num_heads: Optional[int] = None, head_dim: int = 128):
         """Static state shared by all captured batch sizes: the 4-byte split-size word and a workspace large
         enough for every (bs, splits_for_batch(bs)) pair (compare fa3_attn_backend.py:154-175)."""
-        self.decode_graph_vars = {"chunk": torch.full((1,), 1 << 20, dtype=torch.int32, device=self.device)}
+        self.decode_graph_vars = {"chunk": torch.full((1,), 1 << 20, dtype=torch.int32, device=self.device),
+                                  "reuse_lens": torch.zeros(max_bs, dtype=torch.int32, device=self.device)}
         self.decode_graph_metadata = {}
         if num_heads is None:
             num_heads = getattr(self, "graph_num_heads", None)
@@ -122,7 +131,8 @@ class HipAttnBackend(AttentionBackend):
     def init_forward_metadata_capture_cuda_graph(self, bs: int, forward_mode):
         if forward_mode.is_extend():
             raise NotImplementedError("extend is not captured in a graph")
-        md = HipAttnMetadata(max_splits=splits_for_batch(bs), chunk_dev=self.decode_graph_vars["chunk"])
+        md = HipAttnMetadata(max_splits=splits_for_batch(bs), chunk_dev=self.decode_graph_vars["chunk"],
+                             reuse_lens=self.decode_graph_vars["reuse_lens"][:bs])
         self.decode_graph_metadata[bs] = md
         self.forward_metadata = md
 
@@ -137,6 +147,14 @@ class HipAttnBackend(AttentionBackend):
             chunk = self._decode_split(seq_lens_cpu, bs, md.max_splits)
             self.decode_graph_vars["chunk"].fill_(chunk)
         self.forward_metadata = md
+
+    def set_graph_reuse_lens(self, shared_prefix_lens: Optional[torch.Tensor]) -> None:
+        """Optional, before a replay: per-request shared-prefix lengths for the cache-policy hint (None = none).
+        Not part of the reference's hook set; a runner that never calls it gets pure streaming reads."""
+        buf = self.decode_graph_vars["reuse_lens"]
+        buf.zero_()
+        if shared_prefix_lens is not None:
+            buf[: shared_prefix_lens.numel()].copy_(shared_prefix_lens)
 
 
 def _as_heads(q: torch.Tensor, num_heads: int, head_dim: int) -> torch.Tensor:

@@ -23,5 +23,5 @@ int check_launch(const char* what) {
 
 }  // namespace msgl
 
-extern "C" int msgl_abi_version(void) { return 1; }
+extern "C" int msgl_abi_version(void) { return 2; }
 extern "C" const char* msgl_last_error(void) { return msgl::g_err; }

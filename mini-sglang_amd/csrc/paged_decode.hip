@@ -48,6 +48,8 @@ struct DecodeParams {
     float* ws_o;   // [bs, max_splits, Hq, 128] unnormalised partial outputs
     float* ws_ml;  // [bs, max_splits, Hq, 2]   (running max in log2 units, running sum)
     const int32_t* chunk_dev;
+    const int32_t* reuse_lens;  // per request: positions below this may be shared with other requests
+    int kv_stream;              // 0: every K/V load is cached; 1: loads at or above reuse_lens are non-temporal
     int chunk;
     int bs, Hq, max_splits;
     float scale_log2e;
@@ -60,6 +62,17 @@ __device__ __forceinline__ int split_chunk(const DecodeParams& p) {
 }
 
 __device__ __forceinline__ uint4 ld16(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+// K/V row load.  NT = non-temporal hint: rows that no other request re-reads in this launch should not
+// displace the few that are shared (prefix pages of the radix cache) from L2 / the Infinity Cache.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+template <bool NT>
+__device__ __forceinline__ uint4 ld16_kv(const uint16_t* p) {
+    if (NT) {
+        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const uint4*>(p);
+}
 
 // Register ring depth: tiles of K and of V in flight per wave.
 template <int G>
@@ -135,7 +148,9 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
     // refill vb[st].  idx_refill is the table entry of tile n + DEPTH (REFILL only).
     auto tile_step = [&](auto st_tag, auto refill_tag, int n, int idx_refill) {
         constexpr int st = decltype(st_tag)::value;
-        constexpr bool REFILL = decltype(refill_tag)::value;
+        constexpr int RF = decltype(refill_tag)::value;  // 0: no refill, 1: refill with cached loads, 2: non-temporal
+        constexpr bool REFILL = RF != 0;
+        constexpr bool NT = RF == 2;
         int64_t off[4];
         if (REFILL) tile_offsets(idx_refill, off);
 
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
                 // this stage's K registers are free: refill them before the remaining softmax / P.V work
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) kb[st][i] = ld16(kbase + off[i]);
+                for (int i = 0; i < 4; ++i) kb[st][i] = ld16_kv<NT>(kbase + off[i]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             float pr[GS][4];
@@ -203,12 +218,13 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
         if (REFILL) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vb[st][i] = ld16(vbase + off[i]);
+            for (int i = 0; i < 4; ++i) vb[st][i] = ld16_kv<NT>(vbase + off[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    using T_ = std::true_type;
-    using F_ = std::false_type;
+    using F_ = std::integral_constant<int, 0>;   // no refill
+    using T_ = std::integral_constant<int, 1>;   // refill, cached loads
+    using NT_ = std::integral_constant<int, 2>;  // refill, non-temporal loads
 
     // prologue: fill the ring with own tiles 0 .. DEPTH-1 (tiles past the end re-read the last valid one)
     int idx_next;  // table entry of the next tile to refill
@@ -218,17 +234,27 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
             int64_t off[4];
             tile_offsets(load_index(st), off);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) kb[st][i] = ld16(kbase + off[i]);
+            for (int i = 0; i < 4; ++i) kb[st][i] = ld16_kv<false>(kbase + off[i]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vb[st][i] = ld16(vbase + off[i]);
+            for (int i = 0; i < 4; ++i) vb[st][i] = ld16_kv<false>(vbase + off[i]);
         }
         idx_next = load_index(DEPTH);
     }
 
     // steady state: every tile of the group has a refill target inside the split.  The body is
     // branch free, so the compiler's wait counts stay exact and loads stay in flight across tiles.
+    // Tiles whose refill target starts below reuse_len (positions other requests may share) use cached
+    // loads, the rest stream with the non-temporal hint.
+    const int reuse_len = !p.kv_stream ? 0x7fffffff : (p.reuse_lens ? p.reuse_lens[b] : 0);
+    int n_cached = 0;  // own tiles [0, n_cached) refill with cached loads
+    if (reuse_len > t0) {
+        const int tiles_below = (min(reuse_len, t1) - t0 + kTile - 1) / kTile;      // split tiles starting below reuse_len
+        const int own_below = (tiles_below > sub) ? (tiles_below - sub + WPH - 1) / WPH : 0;
+        n_cached = max(0, own_below - DEPTH);
+        n_cached = (n_cached + DEPTH - 1) / DEPTH * DEPTH;
+    }
     int n0 = 0;
-    for (; n0 + 2 * DEPTH <= my_tiles; n0 += DEPTH) {
+    for (; n0 + 2 * DEPTH <= my_tiles && n0 < n_cached; n0 += DEPTH) {
         if constexpr (DEPTH >= 1) {
             const int idx_r = idx_next;
             idx_next = load_index(n0 + 0 + DEPTH + 1);
@@ -238,6 +264,18 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
             const int idx_r = idx_next;
             idx_next = load_index(n0 + 1 + DEPTH + 1);
             tile_step(std::integral_constant<int, 1>{}, T_{}, n0 + 1, idx_r);
+        }
+    }
+    for (; n0 + 2 * DEPTH <= my_tiles; n0 += DEPTH) {
+        if constexpr (DEPTH >= 1) {
+            const int idx_r = idx_next;
+            idx_next = load_index(n0 + 0 + DEPTH + 1);
+            tile_step(std::integral_constant<int, 0>{}, NT_{}, n0 + 0, idx_r);
+        }
+        if constexpr (DEPTH >= 2) {
+            const int idx_r = idx_next;
+            idx_next = load_index(n0 + 1 + DEPTH + 1);
+            tile_step(std::integral_constant<int, 1>{}, NT_{}, n0 + 1, idx_r);
         }
     }
     // tail: at most 2*DEPTH - 1 tiles; refill only where the target exists
@@ -429,7 +467,7 @@ extern "C" int msgl_paged_decode(const void* q, int64_t q_stride, const void* k_
                                  const int32_t* req_pool_indices, const int32_t* seq_lens, void* out,
                                  int64_t out_stride, void* workspace, size_t workspace_bytes, int bs, int Hq, int Hkv,
                                  int D, int page_size, float scale, int max_splits, int chunk_tokens,
-                                 const int32_t* chunk_dev, void* stream) {
+                                 const int32_t* chunk_dev, int kv_stream, const int32_t* reuse_lens, void* stream) {
     if (bs == 0) return MSGL_OK;
     MSGL_REQUIRE(bs > 0, "msgl_paged_decode: bs=%d", bs);
     MSGL_REQUIRE(D == kD, "msgl_paged_decode: head dim %d unsupported (128 only)", D);
@@ -469,6 +507,8 @@ extern "C" int msgl_paged_decode(const void* q, int64_t q_stride, const void* k_
     p.ws_o = static_cast<float*>(workspace);
     p.ws_ml = p.ws_o ? p.ws_o + (size_t)bs * max_splits * Hq * D : nullptr;
     p.chunk_dev = chunk_dev;
+    p.reuse_lens = reuse_lens;
+    p.kv_stream = kv_stream ? 1 : 0;
     p.chunk = chunk_tokens;
     p.bs = bs;
     p.Hq = Hq;

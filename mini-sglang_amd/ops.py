@@ -93,8 +93,13 @@ def paged_decode(
     max_splits: int = 1,
     chunk_tokens: int = 0,
     chunk_dev: Optional[torch.Tensor] = None,
+    kv_stream: bool = True,
+    reuse_lens: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
-    """Decode attention for q [bs, Hq, D] over the paged pool; returns [bs, Hq, D] bf16."""
+    """Decode attention for q [bs, Hq, D] over the paged pool; returns [bs, Hq, D] bf16.
+
+    kv_stream: read K/V with the non-temporal hint, except positions below reuse_lens[b] (prefix slots other
+    requests share), which stay cacheable.  A pure performance hint."""
     _dev_bf16(q, "q")
     _dev_i32(req_pool_indices, "req_pool_indices"), _dev_i32(seq_lens, "seq_lens")
     _need(q.dim() == 3 and q.stride(2) == 1 and q.stride(1) == q.shape[2], "q must be [bs, Hq, D] with dense heads")
@@ -116,6 +121,9 @@ def paged_decode(
             workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
         _need(workspace.is_cuda and workspace.is_contiguous() and workspace.numel() * workspace.element_size() >= need,
               f"workspace must hold {need} bytes")
+    if reuse_lens is not None:
+        _dev_i32(reuse_lens, "reuse_lens")
+        _need(reuse_lens.numel() == bs, "reuse_lens must have bs entries")
     if chunk_dev is not None:
         _dev_i32(chunk_dev, "chunk_dev")
     elif chunk_tokens <= 0:
@@ -130,7 +138,8 @@ def paged_decode(
         workspace.data_ptr() if workspace is not None else None,
         workspace.numel() * workspace.element_size() if workspace is not None else 0,
         bs, Hq, Hkv, D, page_size, float(scale), max_splits, int(chunk_tokens),
-        chunk_dev.data_ptr() if chunk_dev is not None else None, _stream()))
+        chunk_dev.data_ptr() if chunk_dev is not None else None, 1 if kv_stream else 0,
+        reuse_lens.data_ptr() if reuse_lens is not None else None, _stream()))
     return out
 
 

@@ -78,6 +78,9 @@ class BatchInfo:
     prefix_seq_lens: torch.Tensor = None    # int32 [bs] (extend only)
     out_cache_loc: torch.Tensor = None      # int32 [num new tokens]
     req_pool_indices: torch.Tensor = None   # int32 [bs]
+    # int32 [bs]: leading positions whose slots came from the prefix cache, i.e. may be shared with other requests
+    # (a cache-policy hint for decode attention; None = unknown / nothing shared)
+    shared_prefix_lens: torch.Tensor = None
     req_to_token_pool: object = None
     page_allocator: object = None
     kv_cache_pool: object = None
@@ -161,6 +164,7 @@ class BatchInfo:
         self.seq_lens = self.seq_lens_cpu.to(dev)
         self.prefix_seq_lens = torch.tensor(prefix_lens, dtype=torch.int32).to(dev)
         self.input_seq_lens = self.seq_lens - self.prefix_seq_lens
+        self.shared_prefix_lens = self.prefix_seq_lens.clone() if any(prefix_lens) else None
         self.out_cache_loc = new_slots.to(dev)
 
     # ------------------------------------------------------------------ decode
@@ -204,6 +208,12 @@ class BatchInfo:
         self.seq_lens_cpu = torch.cat([self.seq_lens_cpu, other.seq_lens_cpu])
         self.req_pool_indices = torch.cat([self.req_pool_indices, other.req_pool_indices])
         self.out_cache_loc = torch.cat([self.out_cache_loc, other.out_cache_loc])
+        if self.shared_prefix_lens is not None or other.shared_prefix_lens is not None:
+            a = self.shared_prefix_lens if self.shared_prefix_lens is not None else torch.zeros(
+                len(self.reqs) - len(other.reqs), dtype=torch.int32, device=self.seq_lens.device)
+            b = other.shared_prefix_lens if other.shared_prefix_lens is not None else torch.zeros(
+                len(other.reqs), dtype=torch.int32, device=self.seq_lens.device)
+            self.shared_prefix_lens = torch.cat([a, b])
 
     def filter_reqs(self, keep_indices: List[int]) -> None:
         """batch_info.py:319-342 (keep form)."""
@@ -212,3 +222,5 @@ class BatchInfo:
         self.seq_lens = self.seq_lens[idx.to(self.seq_lens.device)]
         self.seq_lens_cpu = self.seq_lens_cpu[idx]
         self.req_pool_indices = self.req_pool_indices[idx.to(self.req_pool_indices.device)]
+        if self.shared_prefix_lens is not None:
+            self.shared_prefix_lens = self.shared_prefix_lens[idx.to(self.shared_prefix_lens.device)]

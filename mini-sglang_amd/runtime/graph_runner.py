@@ -84,6 +84,8 @@ class HipGraphRunner:
         self.seq_lens[:raw].copy_(batch.seq_lens)
         self.out_cache_loc[:raw].copy_(batch.out_cache_loc)
         self.req_pool_indices[:raw].copy_(batch.req_pool_indices)
+        if hasattr(self.mr.attn_backend, "set_graph_reuse_lens"):
+            self.mr.attn_backend.set_graph_reuse_lens(batch.shared_prefix_lens)
         self.mr.attn_backend.init_forward_metadata_replay_cuda_graph(
             bs, req_pool_indices=self.req_pool_indices, seq_lens=self.seq_lens, seq_lens_cpu=batch.seq_lens_cpu,
             forward_mode=batch.forward_mode)

@@ -27,7 +27,11 @@ def run(name, Hq, Hkv, ps, seq_lens, groups=None, prefix=None, layers=4, steps=2
     ch = chunk or ops.pick_split(max(seq_lens), sum(seq_lens), bs, ms_)
     ws = torch.empty(max(16, ops.decode_workspace_bytes(bs, Hq, D, ms_)), dtype=torch.uint8, device=dev)
     out = torch.empty_like(q)
-    f = lambda i: ops.paged_decode(q, pools[i % layers][0], pools[i % layers][1], r2t, idx, sl, D ** -0.5, ps, out=out, workspace=ws, max_splits=ms_, chunk_tokens=ch)
+    reuse = torch.tensor([prefix[g] for g in groups], dtype=torch.int32, device=dev) if groups is not None else None
+    stream = os.environ.get("KV_STREAM", "1") == "1"
+    ms_ = max(1, min(ms_, -(-max(seq_lens) // ch)))
+    f = lambda i: ops.paged_decode(q, pools[i % layers][0], pools[i % layers][1], r2t, idx, sl, D ** -0.5, ps, out=out, workspace=ws, max_splits=ms_, chunk_tokens=ch,
+                                   kv_stream=stream, reuse_lens=reuse if os.environ.get("REUSE", "1") == "1" else None)
     for i in range(5): f(i)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

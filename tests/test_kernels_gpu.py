@@ -124,7 +124,12 @@ def test_decode_shared_prefix_rows():
     # rows of a group really share slots
     r2t, idx = case["r2t"], case["req_idx"].long()
     assert torch.equal(r2t[idx[0], :256], r2t[idx[1], :256]) and torch.equal(r2t[idx[0], :256], r2t[idx[2], :256])
-    check_decode(case, run_decode(case, ps, max_splits=8, chunk_tokens=128))
+    base = run_decode(case, ps, max_splits=8, chunk_tokens=128)
+    check_decode(case, base)
+    # the cache-policy hint never changes results: all-cached, all-streamed, streamed beyond the shared prefix
+    reuse = torch.tensor([prefix[g] for g in groups], dtype=torch.int32, device=DEV)
+    for kw in (dict(kv_stream=False), dict(kv_stream=True), dict(kv_stream=True, reuse_lens=reuse)):
+        assert torch.equal(run_decode(case, ps, max_splits=8, chunk_tokens=128, **kw), base)
 
 
 def test_decode_long_context_split():

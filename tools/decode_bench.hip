@@ -41,7 +41,7 @@ __global__ void fill_bf16(uint16_t* p, size_t n, uint64_t seed) {
 
 int main(int argc, char** argv) {
     int bs = 256, ctx = 8192, ps = 16, hq = 32, hkv = 8, layers = 4, steps = 20, warmup = 5, chunk = 4096, splits = 8,
-        interleaved = 1;
+        interleaved = 1, kv_stream = 1;
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string a = argv[i];
         const int v = atoi(argv[i + 1]);
@@ -56,6 +56,7 @@ int main(int argc, char** argv) {
         else if (a == "--chunk") chunk = v;
         else if (a == "--splits") splits = v;
         else if (a == "--interleaved") interleaved = v;
+        else if (a == "--stream") kv_stream = v;
         else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
     }
     const int D = 128;
@@ -120,7 +121,7 @@ int main(int argc, char** argv) {
         const int l = i % layers;
         const int rc = msgl_paged_decode(qbuf[l], (int64_t)hq * D, kbuf[l], vbuf[l], cache_stride, d_r2t, max_ctx, d_idx, d_seq,
                                          d_out, (int64_t)hq * D, d_ws, ws_bytes, bs, hq, hkv, D, ps, 0.08838834764831845f,
-                                         splits, chunk, nullptr, st);
+                                         splits, chunk, nullptr, kv_stream, nullptr, st);
         if (rc != 0) {
             fprintf(stderr, "msgl_paged_decode: %d %s\n", rc, msgl_last_error());
             exit(1);
