@@ -54,6 +54,9 @@ constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;
 constexpr int DPP_ROW_MIRROR = 0x140;
+constexpr int DPP_ROW_ROR8 = 0x128;    // rotate the 16-lane row by 8: the other octet
+constexpr int DPP_ROW_BCAST0 = 0x150;  // row_newbcast: lane 0 of the row to all of its lanes
+constexpr int DPP_ROW_BCAST8 = 0x158;  // row_newbcast: lane 8 of the row to all of its lanes
 
 // Sum over the 16 lanes of a DPP row; every lane of the row gets the total.
 __device__ __forceinline__ float row16_sum(float x) {
@@ -61,6 +64,14 @@ __device__ __forceinline__ float row16_sum(float x) {
     x += dpp_f32<DPP_XOR2>(x);
     x += dpp_f32<DPP_ROW_HALF_MIRROR>(x);  // quads hold equal values: mirror == xor 4
     x += dpp_f32<DPP_ROW_MIRROR>(x);       // halves hold equal values: mirror == xor 8
+    return x;
+}
+
+// Sum over the 8 lanes of an octet (half a DPP row); every lane of the octet gets the total.
+__device__ __forceinline__ float octet_sum(float x) {
+    x += dpp_f32<DPP_XOR1>(x);
+    x += dpp_f32<DPP_XOR2>(x);
+    x += dpp_f32<DPP_ROW_HALF_MIRROR>(x);  // quads hold equal values: mirror == xor 4
     return x;
 }
 

@@ -102,20 +102,28 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane >> 4;   // DPP row = token within a group of 4
-    const int c = lane & 15;   // 16-byte column chunk of the 256-byte head row
-    const int h = wave / WPH;  // local kv head
+    // Lane roles.  K rows are read by OCTETS: 8 lanes x 16 B cover one 128-byte half row, a load
+    // instruction covers 8 tokens, and a score needs only a 3-step reduction.  V rows are read by DPP ROWS:
+    // 16 lanes x 16 B cover one 256-byte row, so each lane accumulates 8 output columns per query head.
+    // Row j of the wave owns tile tokens 8t + 2j + b (t, b in {0, 1}) in both layouts.
+    const int j = lane >> 4;        // DPP row
+    const int c = lane & 15;        // V: 16-byte column chunk of the 256-byte head row
+    const int o = lane >> 3;        // K: octet = token 8t + o of the tile
+    const int s8 = lane & 7;        // K: 16-byte chunk inside a 128-byte half row
+    const int h = wave / WPH;       // local kv head
     const int sub = wave - h * WPH;
     // this wave's tiles are sub, sub + WPH, ...; "n" below counts them
     const int my_tiles = (ntiles > sub) ? (ntiles - sub + WPH - 1) / WPH : 0;
 
     const int32_t* r2t_row = p.r2t + (int64_t)p.req_idx[b] * p.r2t_stride;
-    const uint16_t* kbase = p.kc + h * kD + c * 8;
+    const uint16_t* kbase = p.kc + h * kD + s8 * 8;
     const uint16_t* vbase = p.vc + h * kD + c * 8;
 
-    uint4 qv[G];
+    uint4 qv[G][2];  // query columns [64k + 8 s8, +8) of head g, packed bf16
 #pragma unroll
-    for (int g = 0; g < G; ++g) qv[g] = ld16(p.q + (int64_t)b * p.q_stride + (h * G + g) * kD + c * 8);
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) qv[g][k] = ld16(p.q + (int64_t)b * p.q_stride + (h * G + g) * kD + k * 64 + s8 * 8);
 
     float m[G], l[G], acc[G][8];
 #pragma unroll
@@ -134,16 +142,24 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
         tok = min(tok, t1 - 1);
         return r2t_row[tok];
     };
-    // element offsets of the 4 rows this lane loads for a tile whose table entry is idx
-    auto tile_offsets = [&](int idx, int64_t (&off)[4]) {
+    // element offsets of the rows this lane loads for a tile whose table entry is idx: K tokens 8t + o,
+    // V tokens 8t + 2j + b (instruction i = 2t + b)
+    auto tile_offsets = [&](int idx, int64_t (&koff)[2], int64_t (&voff)[4]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int tk = 8 * t + o;
+            const int slot = PAGED16 ? idx + tk : __shfl(idx, tk & 15, 16);
+            koff[t] = (int64_t)slot * p.cache_stride;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int slot = PAGED16 ? idx + i * 4 + j : __shfl(idx, i * 4 + j, 16);
-            off[i] = (int64_t)slot * p.cache_stride;
+            const int tv = 8 * (i >> 1) + 2 * j + (i & 1);
+            const int slot = PAGED16 ? idx + tv : __shfl(idx, tv, 16);
+            voff[i] = (int64_t)slot * p.cache_stride;
         }
     };
 
-    uint4 kb[DEPTH][4], vb[DEPTH][4];
+    uint4 kb[DEPTH][4], vb[DEPTH][4];  // kb[.][2t + k]: half row k of token 8t + o; vb[.][i]: row of token 8(i>>1) + 2j + (i&1)
     // One tile: scores from kb[st]; refill kb[st] with own tile n + DEPTH; softmax; P.V from vb[st];
     // refill vb[st].  idx_refill is the table entry of tile n + DEPTH (REFILL only).
     auto tile_step = [&](auto st_tag, auto refill_tag, int n, int idx_refill) {
@@ -151,49 +167,54 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
         constexpr int RF = decltype(refill_tag)::value;  // 0: no refill, 1: refill with cached loads, 2: non-temporal
         constexpr bool REFILL = RF != 0;
         constexpr bool NT = RF == 2;
-        int64_t off[4];
-        if (REFILL) tile_offsets(idx_refill, off);
+        int64_t koff[2], voff[4];
+        if (REFILL) tile_offsets(idx_refill, koff, voff);
 
-        const int tok0 = t0 + (sub + n * WPH) * kTile + j;
-        // query heads are taken GS at a time (scores -> softmax -> P.V per group) so that only GS * 4
+        const int tok0 = t0 + (sub + n * WPH) * kTile + o;  // this lane's K token of half t is tok0 + 8t
+        // query heads are taken GS at a time (scores -> softmax -> P.V per group) so that only a few
         // scores and probabilities are live beside the G * 8 accumulators
         constexpr int GS = G < 4 ? G : 4;
 #pragma unroll
         for (int g0 = 0; g0 < G; g0 += GS) {
-            float s[GS][4];
+            float s[GS][2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int t = 0; t < 2; ++t) {
 #pragma unroll
                 for (int gg = 0; gg < GS; ++gg) {
                     const int g = g0 + gg;
-                    float d = dot2_bf16(qv[g].x, kb[st][i].x, 0.f);
-                    d = dot2_bf16(qv[g].y, kb[st][i].y, d);
-                    d = dot2_bf16(qv[g].z, kb[st][i].z, d);
-                    d = dot2_bf16(qv[g].w, kb[st][i].w, d);
-                    d = row16_sum(d);
-                    s[gg][i] = (tok0 + i * 4 < t1) ? d * p.scale_log2e : -INFINITY;
+                    float d = dot2_bf16(qv[g][0].x, kb[st][2 * t].x, 0.f);
+                    d = dot2_bf16(qv[g][0].y, kb[st][2 * t].y, d);
+                    d = dot2_bf16(qv[g][0].z, kb[st][2 * t].z, d);
+                    d = dot2_bf16(qv[g][0].w, kb[st][2 * t].w, d);
+                    d = dot2_bf16(qv[g][1].x, kb[st][2 * t + 1].x, d);
+                    d = dot2_bf16(qv[g][1].y, kb[st][2 * t + 1].y, d);
+                    d = dot2_bf16(qv[g][1].z, kb[st][2 * t + 1].z, d);
+                    d = dot2_bf16(qv[g][1].w, kb[st][2 * t + 1].w, d);
+                    d = octet_sum(d);
+                    s[gg][t] = (tok0 + 8 * t < t1) ? d * p.scale_log2e : -INFINITY;
                 }
             }
             if (REFILL && g0 + GS >= G) {
                 // this stage's K registers are free: refill them before the remaining softmax / P.V work
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) kb[st][i] = ld16_kv<NT>(kbase + off[i]);
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) kb[st][2 * t + k] = ld16_kv<NT>(kbase + koff[t] + k * 64);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            float pr[GS][4];
+            float pr[GS][2];
 #pragma unroll
             for (int gg = 0; gg < GS; ++gg) {
                 const int g = g0 + gg;
-                const float mt = fmaxf(fmaxf(s[gg][0], s[gg][1]), fmaxf(s[gg][2], s[gg][3]));
+                float mt = fmaxf(s[gg][0], s[gg][1]);
+                mt = fmaxf(mt, dpp_f32<DPP_ROW_ROR8>(mt));  // the row's other octet
                 const float mn = fmaxf(m[g], mt);
                 const float alpha = fast_exp2(m[g] - mn);
-                float ps = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    pr[gg][i] = fast_exp2(s[gg][i] - mn);
-                    ps += pr[gg][i];
-                }
+                pr[gg][0] = fast_exp2(s[gg][0] - mn);
+                pr[gg][1] = fast_exp2(s[gg][1] - mn);
+                float ps = pr[gg][0] + pr[gg][1];
+                ps += dpp_f32<DPP_ROW_ROR8>(ps);
                 l[g] = l[g] * alpha + ps;
                 m[g] = mn;
 #pragma unroll
@@ -202,14 +223,18 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t w[4] = {vb[st][i].x, vb[st][i].y, vb[st][i].z, vb[st][i].w};
+                float pb[GS];  // probability of token 8(i>>1) + 2j + (i&1): held by the row's octet (i&1)
+#pragma unroll
+                for (int gg = 0; gg < GS; ++gg)
+                    pb[gg] = (i & 1) ? dpp_f32<DPP_ROW_BCAST8>(pr[gg][i >> 1]) : dpp_f32<DPP_ROW_BCAST0>(pr[gg][i >> 1]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float lo = bf16_lo(w[e]), hi = bf16_hi(w[e]);
 #pragma unroll
                     for (int gg = 0; gg < GS; ++gg) {
                         const int g = g0 + gg;
-                        acc[g][2 * e] = fmaf(pr[gg][i], lo, acc[g][2 * e]);
-                        acc[g][2 * e + 1] = fmaf(pr[gg][i], hi, acc[g][2 * e + 1]);
+                        acc[g][2 * e] = fmaf(pb[gg], lo, acc[g][2 * e]);
+                        acc[g][2 * e + 1] = fmaf(pb[gg], hi, acc[g][2 * e + 1]);
                     }
                 }
             }
@@ -218,7 +243,7 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
         if (REFILL) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vb[st][i] = ld16_kv<NT>(vbase + off[i]);
+            for (int i = 0; i < 4; ++i) vb[st][i] = ld16_kv<NT>(vbase + voff[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -231,12 +256,14 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
     {
 #pragma unroll
         for (int st = 0; st < DEPTH; ++st) {
-            int64_t off[4];
-            tile_offsets(load_index(st), off);
+            int64_t koff[2], voff[4];
+            tile_offsets(load_index(st), koff, voff);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) kb[st][i] = ld16_kv<false>(kbase + off[i]);
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vb[st][i] = ld16_kv<false>(vbase + off[i]);
+                for (int k = 0; k < 2; ++k) kb[st][2 * t + k] = ld16_kv<false>(kbase + koff[t] + k * 64);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vb[st][i] = ld16_kv<false>(vbase + voff[i]);
         }
         idx_next = load_index(DEPTH);
     }
