@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--layout", default="interleaved", choices=["interleaved", "split"])
     ap.add_argument("--max-splits", type=int, default=0, help="0 = backend default for the batch size")
     ap.add_argument("--chunk", type=int, default=0, help="0 = backend default")
+    ap.add_argument("--graph-grid", action="store_true", help="launch the full bs x max_splits grid a captured graph uses")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-e2e", action="store_true", help="skip the full-model decode tok/s measurement")
@@ -95,6 +96,10 @@ def main():
     out = torch.empty((bs, Hq, D), dtype=torch.bfloat16, device=dev)
     max_splits = args.max_splits or splits_for_batch(bs)
     chunk = args.chunk or ops.pick_split(S, S * bs, bs, max_splits)
+    if not args.graph_grid:
+        # an eager call knows the longest context on the host and launches only the splits it needs, exactly as
+        # HipAttnBackend.init_forward_metadata does; --graph-grid keeps the length-independent grid of a captured step
+        max_splits = max(1, min(max_splits, -(-S // chunk)))
     ws = torch.empty(max(ops.decode_workspace_bytes(bs, Hq, D, max_splits), 16), dtype=torch.uint8, device=dev)
     scale = D ** -0.5
 
