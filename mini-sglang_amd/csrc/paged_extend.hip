@@ -34,7 +34,7 @@ struct ExtendParams {
     int64_t q_stride;
     const uint16_t* kc;
     const uint16_t* vc;
-    int64_t cache_stride;
+    uint32_t cache_stride;
     const int32_t* r2t;
     int64_t r2t_stride;
     const int32_t* req_idx;
@@ -44,6 +44,7 @@ struct ExtendParams {
     int64_t out_stride;
     int tiles_per_req;
     int bs;
+    int hkv;
     int group;  // query heads per kv head
     float scale_log2e;
 };
@@ -57,14 +58,28 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 struct StageRegs {
     u32x4_t k0, k1, k2, k3, v0, v1, v2, v3;
 };
+struct StageSlots {
+    uint32_t s0, s1, s2, s3;
+};
 
-__device__ __forceinline__ StageRegs stage_load(const uint16_t* kcol, const uint16_t* vcol, int64_t cache_stride,
-                                                const int32_t* r2t_row, int kt, int skey, int kv_len) {
+// Pool slots of the four keys this thread stages for tile kt.  Fetched one tile ahead of the rows
+// themselves, so the row loads never wait on the page-table read.
+__device__ __forceinline__ StageSlots stage_slots(const int32_t* r2t_row, int kt, int skey, int kv_len) {
     const int base = kt * kBN + skey;
-    const int64_t o0 = (int64_t)r2t_row[min(base, kv_len - 1)] * cache_stride;
-    const int64_t o1 = (int64_t)r2t_row[min(base + 16, kv_len - 1)] * cache_stride;
-    const int64_t o2 = (int64_t)r2t_row[min(base + 32, kv_len - 1)] * cache_stride;
-    const int64_t o3 = (int64_t)r2t_row[min(base + 48, kv_len - 1)] * cache_stride;
+    StageSlots r;
+    r.s0 = (uint32_t)r2t_row[min(base, kv_len - 1)];
+    r.s1 = (uint32_t)r2t_row[min(base + 16, kv_len - 1)];
+    r.s2 = (uint32_t)r2t_row[min(base + 32, kv_len - 1)];
+    r.s3 = (uint32_t)r2t_row[min(base + 48, kv_len - 1)];
+    return r;
+}
+
+__device__ __forceinline__ StageRegs stage_load(const uint16_t* kcol, const uint16_t* vcol, uint32_t cache_stride,
+                                                const StageSlots& sl) {
+    const uint64_t o0 = (uint64_t)sl.s0 * cache_stride;
+    const uint64_t o1 = (uint64_t)sl.s1 * cache_stride;
+    const uint64_t o2 = (uint64_t)sl.s2 * cache_stride;
+    const uint64_t o3 = (uint64_t)sl.s3 * cache_stride;
     StageRegs r;
     r.k0 = *reinterpret_cast<const u32x4_t*>(kcol + o0);
     r.v0 = *reinterpret_cast<const u32x4_t*>(vcol + o0);
@@ -91,17 +106,32 @@ __device__ __forceinline__ void stage_write(char* lds_k, char* lds_v, int skey, 
     *reinterpret_cast<u32x4_t*>(vd + 48 * kVRow) = r.v3;
 }
 
-__global__ __launch_bounds__(256) void paged_extend_kernel(ExtendParams p) {
+// max over the two lanes that share a query column (lane, lane ^ 32): one v_permlane32_swap
+__device__ __forceinline__ float max_with_lane_xor32(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
+template <bool B>
+struct BoolTag {
+    static constexpr bool value = B;
+};
+
+__global__ __launch_bounds__(256, 2) void paged_extend_kernel(ExtendParams p) {
     __shared__ __attribute__((aligned(16))) char lds[kBN * kKRow + kBN * kVRow];
     char* lds_k = lds;
     char* lds_v = lds + kBN * kKRow;
 
-    // x = tile-major over requests, last (heaviest under the causal mask) query tile first, so the long
-    // blocks start early and the short ones fill the tail
-    const int b = blockIdx.x % p.bs;
-    const int qt = p.tiles_per_req - 1 - blockIdx.x / p.bs;
-    const int hq = blockIdx.y;
-    const int hk = hq / p.group;
+    // Block order: the last (heaviest under the causal mask) query tile of every request and head first,
+    // so the long blocks start early and the short ones fill the tail.  The kv head varies fastest: with
+    // 8 kv heads the `group` blocks that share a K/V stream run on the same XCD back to back.
+    const int idx = blockIdx.x;
+    const int hk = idx % p.hkv;
+    const int g = (idx / p.hkv) % p.group;
+    const int hq = hk * p.group + g;
+    const int b = (idx / (p.hkv * p.group)) % p.bs;
+    const int qt = p.tiles_per_req - 1 - idx / (p.hkv * p.group * p.bs);
     const int q0 = p.cu_q[b];
     const int Sq = p.cu_q[b + 1] - q0;
     if (qt * kBM >= Sq) return;
@@ -134,90 +164,104 @@ __global__ __launch_bounds__(256) void paged_extend_kernel(ExtendParams p) {
     for (int d = 0; d < 4; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m = kNegBigE, l = 0.f;
+    float m = kNegBigE, l = 0.f;  // m is in the scaled (log2) domain
+
+    const int g1 = (lane >> 4) & 1, iq = (lane & 15) >> 2, ip = lane & 3;
+    const char* k_lane = lds_k + n * kKRow;                                         // + sb*32 rows, swizzled chunk
+    const char* v_lane = lds_v + (4 * h + iq) * kVRow + (16 * g1 + 4 * ip) * 2;     // + key-row and column offsets
+
+    // one 32-key block: S^T, online softmax, O^T update
+    auto block = [&](auto masked, int sb, int kb) {
+        constexpr bool MASKED = decltype(masked)::value;
+        // ---- S^T = K . Q^T ----
+        f32x16_t st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        const char* krow = k_lane + sb * 32 * kKRow;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const uint4 a = *reinterpret_cast<const uint4*>(krow + (((ks * 2 + h) ^ (n & 15)) << 4));
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(qf[ks]), st, 0, 0, 0);
+        }
+        // ---- mask + online softmax (query on the lane, keys in registers); raw scores, scale folded into the exp ----
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kpos = kb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                st[r] = (kpos > qpos) ? -INFINITY : st[r];
+            }
+        }
+        float mx = fmaxf(st[0], st[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(st[r], st[r + 1]));
+        mx = max_with_lane_xor32(mx);
+        const float mn = fmaxf(m, mx * p.scale_log2e);
+        const float alpha = fast_exp2(m - mn);
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = fast_exp2(__builtin_fmaf(st[r], p.scale_log2e, -mn));
+        // P^T fragments: registers 8s..8s+7 are k-step s; element j is key 16s + 8(j>>2) + 4h + (j&3)
+        uint4 pf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            pf[s] = make_uint4(pack_bf16(st[8 * s + 0], st[8 * s + 1]), pack_bf16(st[8 * s + 2], st[8 * s + 3]),
+                               pack_bf16(st[8 * s + 4], st[8 * s + 5]), pack_bf16(st[8 * s + 6], st[8 * s + 7]));
+        // row sum of the ROUNDED probabilities (the values the matrix product uses), two per v_dot2c
+        constexpr uint32_t kOnes = 0x3F803F80u;
+        float ps0 = dot2_bf16(pf[0].x, kOnes, 0.f), ps1 = dot2_bf16(pf[1].x, kOnes, 0.f);
+        ps0 = dot2_bf16(pf[0].y, kOnes, ps0), ps1 = dot2_bf16(pf[1].y, kOnes, ps1);
+        ps0 = dot2_bf16(pf[0].z, kOnes, ps0), ps1 = dot2_bf16(pf[1].z, kOnes, ps1);
+        ps0 = dot2_bf16(pf[0].w, kOnes, ps0), ps1 = dot2_bf16(pf[1].w, kOnes, ps1);
+        l = l * alpha + (ps0 + ps1);  // per-lane partial sum; halves are added after the loop
+        if (!__all(alpha == 1.0f)) {  // the running max settles after a few tiles: usually nothing to rescale
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const char* va = v_lane + (sb * 32 + 16 * s) * kVRow + d * 64;
+                const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(va));
+                const short4_t hi =
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(va + 8 * kVRow));
+                typedef __attribute__((ext_vector_type(8))) short short8_t;
+                short8_t a;
+                a.lo = lo;
+                a.hi = hi;
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), as_bf16x8(pf[s]), o[d], 0, 0, 0);
+            }
+        }
+    };
 
     // staging: thread owns 16-byte chunk c16 of keys skey, skey+16, skey+32, skey+48 of a tile
     const int c16 = tid & 15;
     const int skey = tid >> 4;
     const uint16_t* kcol = p.kc + hk * kHD + c16 * 8;
     const uint16_t* vcol = p.vc + hk * kHD + c16 * 8;
-    StageRegs stg = stage_load(kcol, vcol, p.cache_stride, r2t_row, 0, skey, kv_len);
+    StageSlots slots = stage_slots(r2t_row, 0, skey, kv_len);
+    StageRegs stg = stage_load(kcol, vcol, p.cache_stride, slots);
+    slots = stage_slots(r2t_row, min(1, nkt - 1), skey, kv_len);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();  // every wave is done reading the previous tile
         stage_write(lds_k, lds_v, skey, c16, stg);
         __syncthreads();
-        stg = stage_load(kcol, vcol, p.cache_stride, r2t_row, min(kt + 1, nkt - 1), skey, kv_len);  // last tile: harmless re-read
+        stg = stage_load(kcol, vcol, p.cache_stride, slots);  // tile kt+1 (last tile: harmless re-read)
+        slots = stage_slots(r2t_row, min(kt + 2, nkt - 1), skey, kv_len);
 
         const int k0 = kt * kBN;
+        if (k0 + kBN - 1 <= prefix + row0) {  // wave-uniform: every key of the tile is visible to every row
+#pragma unroll 1  // one copy of the block: unrolled, the two copies' operand reads interleave and spill
+            for (int sb = 0; sb < 2; ++sb) block(BoolTag<false>{}, sb, k0 + sb * 32);
+        } else {
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-            const int kb = k0 + sb * 32;               // first key position of this 32-key block
-            if (kb > prefix + row0 + 31) continue;     // wave-uniform: block entirely above the diagonal
-            // ---- S^T = K . Q^T ----
-            f32x16_t st;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = 0.f;
-            const int key = sb * 32 + n;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const uint4 a = *reinterpret_cast<const uint4*>(lds_k + key * kKRow + (((ks * 2 + h) ^ (key & 15)) << 4));
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(qf[ks]), st, 0, 0, 0);
-            }
-            // ---- mask + online softmax (query on the lane, keys in registers) ----
-            const bool diag = (kb + 31 > prefix + row0);  // wave-uniform: some (key, query) pair is masked
-            float mx = kNegBigE;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = st[r] * p.scale_log2e;
-                if (diag) {
-                    const int kpos = kb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    s = (kpos > qpos) ? -INFINITY : s;
-                }
-                st[r] = s;
-                mx = fmaxf(mx, s);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mn = fmaxf(m, mx);
-            const float alpha = fast_exp2(m - mn);
-            m = mn;
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                st[r] = fast_exp2(st[r] - mn);
-                ps += st[r];
-            }
-            l = l * alpha + ps;  // per-lane partial sum; halves are added after the loop
-            if (!__all(alpha == 1.0f)) {  // the running max settles after a few tiles: usually nothing to rescale
-#pragma unroll
-                for (int d = 0; d < 4; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            }
-            // P^T fragments: registers 8s..8s+7 are k-step s; element j is key 16s + 8(j>>2) + 4h + (j&3)
-            uint4 pf[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-                pf[s] = make_uint4(pack_bf16(st[8 * s + 0], st[8 * s + 1]), pack_bf16(st[8 * s + 2], st[8 * s + 3]),
-                                   pack_bf16(st[8 * s + 4], st[8 * s + 5]), pack_bf16(st[8 * s + 6], st[8 * s + 7]));
-            // ---- O^T += V^T . P^T ----
-            const int g1 = (lane >> 4) & 1, iq = (lane & 15) >> 2, ip = lane & 3;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int kr = sb * 32 + 16 * s + 4 * h + iq;  // key row this lane addresses
-                    const char* va = lds_v + kr * kVRow + (d * 32 + 16 * g1 + 4 * ip) * 2;
-                    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) short4_t*)(va));
-                    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) short4_t*)(va + 8 * kVRow));
-                    typedef __attribute__((ext_vector_type(8))) short short8_t;
-                    short8_t a;
-                    a.lo = lo;
-                    a.hi = hi;
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), as_bf16x8(pf[s]), o[d], 0,
-                                                                   0, 0);
-                }
+            for (int sb = 0; sb < 2; ++sb) {
+                const int kb = k0 + sb * 32;            // first key position of this 32-key block
+                if (kb > prefix + row0 + 31) continue;  // wave-uniform: block entirely above the diagonal
+                block(BoolTag<true>{}, sb, kb);
             }
         }
     }
@@ -263,7 +307,8 @@ extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_
     p.q_stride = q_stride;
     p.kc = static_cast<const uint16_t*>(k_cache);
     p.vc = static_cast<const uint16_t*>(v_cache);
-    p.cache_stride = cache_stride;
+    MSGL_REQUIRE(cache_stride < (int64_t)1 << 31, "msgl_paged_extend: cache_stride %lld too large", (long long)cache_stride);
+    p.cache_stride = (uint32_t)cache_stride;
     p.r2t = req_to_token;
     p.r2t_stride = r2t_stride;
     p.req_idx = req_pool_indices;
@@ -273,10 +318,11 @@ extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_
     p.out_stride = out_stride;
     p.tiles_per_req = (max_seqlen_q + kBM - 1) / kBM;
     p.bs = bs;
+    p.hkv = Hkv;
     p.group = Hq / Hkv;
     p.scale_log2e = scale * 1.4426950408889634f;
-    const int64_t gx = (int64_t)bs * p.tiles_per_req;
+    const int64_t gx = (int64_t)bs * p.tiles_per_req * Hq;
     MSGL_REQUIRE(gx <= 0x7fffffff, "msgl_paged_extend: grid too large");
-    hipLaunchKernelGGL(paged_extend_kernel, dim3((unsigned)gx, (unsigned)Hq), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(paged_extend_kernel, dim3((unsigned)gx), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return check_launch("paged_extend_kernel");
 }
