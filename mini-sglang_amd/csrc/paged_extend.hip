@@ -1,32 +1,41 @@
 // Paged extend (prefill) attention for gfx950: variable-length query runs, bottom-right
 // causal mask, K/V gathered from the slot pool through req_to_token.  MFMA bound.
 //
-// Work group = 4 waves = 128 consecutive query rows of one (request, query head); every
-// wave owns 32 rows.  The key axis is walked in tiles of 64 tokens staged in LDS:
+// Work group = 4*NH waves = 128 consecutive query rows of NH query heads that share one kv
+// head (NH = 2 whenever the GQA group is even: both heads consume the same staged K/V tile);
+// every wave owns 32 rows of one head.  The key axis is walked in tiles of 64 tokens staged
+// through registers into a 3-deep LDS ring (one barrier per tile):
 //   S^T = K . Q^T      v_mfma_f32_32x32x16_bf16, A = K rows from LDS (ds_read_b128 on an
 //                      XOR-swizzled image), B = Q^T held in registers for the whole kernel;
-//                      the accumulator has the QUERY on the lane and 16 KEYS in registers,
+//                      the accumulator has the QUERY on the lane and 2 x 16 KEYS in registers,
 //                      so row max / row sum are in-lane plus one exchange with lane ^ 32;
 //   O^T += V^T . P^T   the S^T accumulator, exponentiated and packed to bf16, is already
 //                      the B operand (its register order fixes the key order inside a
 //                      k-step); the matching A operand V^T comes from LDS through
 //                      ds_read_b64_tr_b16 (hardware transpose) on a 320-byte-stride image
 //                      that is bank-conflict free for that read.
-// The next tile's rows are fetched into registers before the MFMAs of the current tile
-// and written to LDS after them, so HBM/L2 latency hides under the matrix work.
+// The loop is software pipelined inside each wave: iteration t issues S^T of tile t+1, then
+// the 16 matrix instructions of O^T for tile t with the softmax arithmetic of tile t+1
+// placed between them, so the vector and matrix pipes run side by side.
 #include "msgl_common.h"
 
 namespace msgl {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(8))) short short8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-constexpr int kBM = 128;          // query rows per work group
+constexpr int kBM = 128;          // query rows per work group (per head)
 constexpr int kBN = 64;           // keys per LDS tile
 constexpr int kHD = 128;          // head dim
 constexpr int kKRow = 256;        // bytes per K row in LDS (swizzled 16-byte chunks)
 constexpr int kVRow = 320;        // bytes per V row in LDS (padded: conflict-free transposed reads)
+constexpr int kKBytes = kBN * kKRow;
+constexpr int kTileBytes = kBN * kKRow + kBN * kVRow;
+constexpr int kStages = 3;
+constexpr int kExtendLds = kStages * kTileBytes;
 constexpr float kNegBigE = -1.0e30f;
 
 struct ExtendParams {
@@ -51,59 +60,11 @@ struct ExtendParams {
 
 __device__ __forceinline__ bf16x8_t as_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
 
-// Staging of one 64-key tile: thread owns 16-byte chunk c16 of keys skey, skey+16, skey+32, skey+48.
-// Positions past the last visible key re-read that key (always a valid slot), so the loads are
-// unconditional; the causal mask discards those columns.
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-struct StageRegs {
-    u32x4_t k0, k1, k2, k3, v0, v1, v2, v3;
-};
-struct StageSlots {
-    uint32_t s0, s1, s2, s3;
-};
-
-// Pool slots of the four keys this thread stages for tile kt.  Fetched one tile ahead of the rows
-// themselves, so the row loads never wait on the page-table read.
-__device__ __forceinline__ StageSlots stage_slots(const int32_t* r2t_row, int kt, int skey, int kv_len) {
-    const int base = kt * kBN + skey;
-    StageSlots r;
-    r.s0 = (uint32_t)r2t_row[min(base, kv_len - 1)];
-    r.s1 = (uint32_t)r2t_row[min(base + 16, kv_len - 1)];
-    r.s2 = (uint32_t)r2t_row[min(base + 32, kv_len - 1)];
-    r.s3 = (uint32_t)r2t_row[min(base + 48, kv_len - 1)];
+// v_max3_f32 on raw matrix-core outputs (fmaxf would first canonicalise each operand with a v_max x, x)
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
-}
-
-__device__ __forceinline__ StageRegs stage_load(const uint16_t* kcol, const uint16_t* vcol, uint32_t cache_stride,
-                                                const StageSlots& sl) {
-    const uint64_t o0 = (uint64_t)sl.s0 * cache_stride;
-    const uint64_t o1 = (uint64_t)sl.s1 * cache_stride;
-    const uint64_t o2 = (uint64_t)sl.s2 * cache_stride;
-    const uint64_t o3 = (uint64_t)sl.s3 * cache_stride;
-    StageRegs r;
-    r.k0 = *reinterpret_cast<const u32x4_t*>(kcol + o0);
-    r.v0 = *reinterpret_cast<const u32x4_t*>(vcol + o0);
-    r.k1 = *reinterpret_cast<const u32x4_t*>(kcol + o1);
-    r.v1 = *reinterpret_cast<const u32x4_t*>(vcol + o1);
-    r.k2 = *reinterpret_cast<const u32x4_t*>(kcol + o2);
-    r.v2 = *reinterpret_cast<const u32x4_t*>(vcol + o2);
-    r.k3 = *reinterpret_cast<const u32x4_t*>(kcol + o3);
-    r.v3 = *reinterpret_cast<const u32x4_t*>(vcol + o3);
-    return r;
-}
-
-__device__ __forceinline__ void stage_write(char* lds_k, char* lds_v, int skey, int c16, const StageRegs& r) {
-    // keys skey + 16 i: (key & 15) == (skey & 15) for every i
-    char* kd = lds_k + skey * kKRow + ((c16 ^ (skey & 15)) << 4);
-    char* vd = lds_v + skey * kVRow + (c16 << 4);
-    *reinterpret_cast<u32x4_t*>(kd) = r.k0;
-    *reinterpret_cast<u32x4_t*>(kd + 16 * kKRow) = r.k1;
-    *reinterpret_cast<u32x4_t*>(kd + 32 * kKRow) = r.k2;
-    *reinterpret_cast<u32x4_t*>(kd + 48 * kKRow) = r.k3;
-    *reinterpret_cast<u32x4_t*>(vd) = r.v0;
-    *reinterpret_cast<u32x4_t*>(vd + 16 * kVRow) = r.v1;
-    *reinterpret_cast<u32x4_t*>(vd + 32 * kVRow) = r.v2;
-    *reinterpret_cast<u32x4_t*>(vd + 48 * kVRow) = r.v3;
 }
 
 // max over the two lanes that share a query column (lane, lane ^ 32): one v_permlane32_swap
@@ -113,25 +74,69 @@ __device__ __forceinline__ float max_with_lane_xor32(float x) {
     return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
 }
 
-template <bool B>
-struct BoolTag {
-    static constexpr bool value = B;
+// Staging of one 64-key tile through registers: thread owns 16-byte chunk c16 of KPT keys
+// skey + i * KSTEP.  Positions past the last visible key re-read that key (always a valid
+// slot), so the loads are unconditional; the causal mask discards those columns.
+template <int KPT>
+struct StageRegs {
+    u32x4_t k[KPT], v[KPT];
+};
+template <int KPT>
+struct StageSlots {
+    uint32_t s[KPT];
 };
 
-__global__ __launch_bounds__(256, 2) void paged_extend_kernel(ExtendParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[kBN * kKRow + kBN * kVRow];
-    char* lds_k = lds;
-    char* lds_v = lds + kBN * kKRow;
+template <int KPT, int KSTEP>
+__device__ __forceinline__ StageSlots<KPT> stage_slots(const int32_t* r2t_row, int kt, int skey, int kv_len) {
+    const int base = kt * kBN + skey;
+    StageSlots<KPT> r;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) r.s[i] = (uint32_t)r2t_row[min(base + i * KSTEP, kv_len - 1)];
+    return r;
+}
+
+template <int KPT>
+__device__ __forceinline__ StageRegs<KPT> stage_load(const uint16_t* kcol, const uint16_t* vcol, uint32_t cache_stride,
+                                                     const StageSlots<KPT>& sl) {
+    StageRegs<KPT> r;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const uint64_t o = (uint64_t)sl.s[i] * cache_stride;
+        r.k[i] = *reinterpret_cast<const u32x4_t*>(kcol + o);
+        r.v[i] = *reinterpret_cast<const u32x4_t*>(vcol + o);
+    }
+    return r;
+}
+
+template <int KPT, int KSTEP>
+__device__ __forceinline__ void stage_write(char* tile, int skey, int c16, const StageRegs<KPT>& r) {
+    // keys skey + i * KSTEP: KSTEP is a multiple of 16, so (key & 15) == (skey & 15) for every i
+    char* kd = tile + skey * kKRow + ((c16 ^ (skey & 15)) << 4);
+    char* vd = tile + kKBytes + skey * kVRow + (c16 << 4);
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        *reinterpret_cast<u32x4_t*>(kd + i * KSTEP * kKRow) = r.k[i];
+        *reinterpret_cast<u32x4_t*>(vd + i * KSTEP * kVRow) = r.v[i];
+    }
+}
+
+constexpr int SG_VALU = 0x002, SG_MFMA = 0x008, SG_DSREAD = 0x100, SG_TRANS = 0x400;
+
+template <int NH>
+__global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams p) {
+    constexpr int KPT = 4 / NH;          // keys staged per thread and tile
+    constexpr int KSTEP = 16 * NH;       // distance between a thread's staged keys
+    extern __shared__ __attribute__((aligned(256))) char lds[];
 
     // Block order: the last (heaviest under the causal mask) query tile of every request and head first,
     // so the long blocks start early and the short ones fill the tail.  The kv head varies fastest: with
-    // 8 kv heads the `group` blocks that share a K/V stream run on the same XCD back to back.
+    // 8 kv heads the blocks that share a K/V stream run on the same XCD back to back.
+    const int hsets = p.group / NH;  // work groups per (kv head, query tile)
     const int idx = blockIdx.x;
     const int hk = idx % p.hkv;
-    const int g = (idx / p.hkv) % p.group;
-    const int hq = hk * p.group + g;
-    const int b = (idx / (p.hkv * p.group)) % p.bs;
-    const int qt = p.tiles_per_req - 1 - idx / (p.hkv * p.group * p.bs);
+    const int hs = (idx / p.hkv) % hsets;
+    const int b = (idx / (p.hkv * hsets)) % p.bs;
+    const int qt = p.tiles_per_req - 1 - idx / (p.hkv * hsets * p.bs);
     const int q0 = p.cu_q[b];
     const int Sq = p.cu_q[b + 1] - q0;
     if (qt * kBM >= Sq) return;
@@ -142,12 +147,16 @@ __global__ __launch_bounds__(256, 2) void paged_extend_kernel(ExtendParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hq = hk * p.group + hs * NH + (wave >> 2);
     const int n = lane & 31;  // query column of the S^T / O^T tiles
     const int h = lane >> 5;
-    const int row0 = qt * kBM + wave * 32;  // first query row of this wave
+    const int row0 = qt * kBM + (wave & 3) * 32;  // first query row of this wave
     const int qrow = row0 + n;
     const bool qvalid = qrow < Sq;
     const int qpos = prefix + qrow;  // last key position this lane's query may see
+    // tiles [0, full_nkt) are visible to every row of the wave, [full_nkt, my_nkt) partly, the rest not at all
+    const int full_nkt = (prefix + row0 + 1) / kBN;
+    const int my_nkt = (row0 < Sq) ? min(nkt, (prefix + row0 + 31) / kBN + 1) : 0;
 
     const int32_t* r2t_row = p.r2t + (int64_t)p.req_idx[b] * p.r2t_stride;
 
@@ -165,105 +174,249 @@ __global__ __launch_bounds__(256, 2) void paged_extend_kernel(ExtendParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m = kNegBigE, l = 0.f;  // m is in the scaled (log2) domain
+    float alpha_pend = 1.0f;      // factor O^T still has to take before the next tile is added to it
+    uint4 pf[4];                  // P^T of the tile whose O^T update is pending: k-step s = keys 16s .. 16s+15
+#pragma unroll
+    for (int s = 0; s < 4; ++s) pf[s] = make_uint4(0, 0, 0, 0);
 
     const int g1 = (lane >> 4) & 1, iq = (lane & 15) >> 2, ip = lane & 3;
-    const char* k_lane = lds_k + n * kKRow;                                         // + sb*32 rows, swizzled chunk
-    const char* v_lane = lds_v + (4 * h + iq) * kVRow + (16 * g1 + 4 * ip) * 2;     // + key-row and column offsets
+    // lane parts of the LDS read addresses (tile base added per tile)
+    const int k_lane = n * kKRow + ((h ^ (n & 15)) << 4);                          // ^ (ks << 5), + 32 rows for block 1
+    const int v_lane = kKBytes + (4 * h + iq) * kVRow + (16 * g1 + 4 * ip) * 2;    // + key rows and column block
 
-    // one 32-key block: S^T, online softmax, O^T update
-    auto block = [&](auto masked, int sb, int kb) {
-        constexpr bool MASKED = decltype(masked)::value;
-        // ---- S^T = K . Q^T ----
-        f32x16_t st;
+    // ---- S^T (both 32-key blocks) of the tile at LDS offset `tile` ----
+    auto qk_tile = [&](int tile, f32x16_t& s0, f32x16_t& s1) {
+        const uint32_t kp = tile + k_lane;  // 256-byte aligned tile base: the chunk swizzle stays an XOR of the offset
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = 0.f;
-        const char* krow = k_lane + sb * 32 * kKRow;
+        for (int r = 0; r < 16; ++r) s0[r] = 0.f, s1[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const uint4 a = *reinterpret_cast<const uint4*>(krow + (((ks * 2 + h) ^ (n & 15)) << 4));
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(qf[ks]), st, 0, 0, 0);
+            const char* ka = lds + (kp ^ (uint32_t)(ks << 5));
+            const uint4 a0 = *reinterpret_cast<const uint4*>(ka);
+            const uint4 a1 = *reinterpret_cast<const uint4*>(ka + 32 * kKRow);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(qf[ks]), s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(qf[ks]), s1, 0, 0, 0);
         }
-        // ---- mask + online softmax (query on the lane, keys in registers); raw scores, scale folded into the exp ----
-        if constexpr (MASKED) {
+    };
+    // V^T fragments of output block d (32 head dims) for the 4 k-steps of the tile
+    auto v_frags = [&](int tile, int d, short8_t (&vf)[4]) {
+        const char* vp = lds + tile + v_lane + d * 64;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kpos = kb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                st[r] = (kpos > qpos) ? -INFINITY : st[r];
-            }
+        for (int s = 0; s < 4; ++s) {
+            vf[s].lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(vp + 16 * s * kVRow));
+            vf[s].hi =
+                __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(vp + (16 * s + 8) * kVRow));
         }
-        float mx = fmaxf(st[0], st[1]);
+    };
+    auto pv_block = [&](int d, const short8_t (&vf)[4]) {
 #pragma unroll
-        for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(st[r], st[r + 1]));
-        mx = max_with_lane_xor32(mx);
-        const float mn = fmaxf(m, mx * p.scale_log2e);
-        const float alpha = fast_exp2(m - mn);
-        m = mn;
+        for (int s = 0; s < 4; ++s)
+            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf[s]), as_bf16x8(pf[s]), o[d], 0, 0, 0);
+    };
+    // the same product k-step major: V^T fragments of k-step s (16 keys) for the 4 output blocks
+    auto v_step = [&](int tile, int s, short8_t (&vf)[4]) {
+        const char* vp = lds + tile + v_lane + 16 * s * kVRow;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = fast_exp2(__builtin_fmaf(st[r], p.scale_log2e, -mn));
-        // P^T fragments: registers 8s..8s+7 are k-step s; element j is key 16s + 8(j>>2) + 4h + (j&3)
-        uint4 pf[2];
+        for (int d = 0; d < 4; ++d) {
+            vf[d].lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(vp + d * 64));
+            vf[d].hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(vp + d * 64 + 8 * kVRow));
+        }
+    };
+    auto pv_step = [&](int s, const short8_t (&vf)[4]) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-            pf[s] = make_uint4(pack_bf16(st[8 * s + 0], st[8 * s + 1]), pack_bf16(st[8 * s + 2], st[8 * s + 3]),
-                               pack_bf16(st[8 * s + 4], st[8 * s + 5]), pack_bf16(st[8 * s + 6], st[8 * s + 7]));
-        // row sum of the ROUNDED probabilities (the values the matrix product uses), two per v_dot2c
+        for (int d = 0; d < 4; ++d)
+            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf[d]), as_bf16x8(pf[s]), o[d], 0, 0, 0);
+    };
+    // softmax pieces on the raw scores st[0..31] (st[16 b + r]: block b, register r); scale folded into the exp
+    auto mask_scores = [&](float (&st)[32], int k0) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int kpos = k0 + 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * h;
+            st[r] = (kpos > qpos) ? -INFINITY : st[r];
+        }
+    };
+    auto row_max = [&](const float (&st)[32]) {
+        float mx = max3_raw(st[0], st[1], st[2]);
+#pragma unroll
+        for (int r = 3; r < 31; r += 2) mx = max3_raw(mx, st[r], st[r + 1]);
+        return max_with_lane_xor32(fmaxf(mx, st[31]));
+    };
+    auto exp_range = [&](float (&st)[32], int lo, int hi, float mn) {
+#pragma unroll
+        for (int r = lo; r < hi; ++r) st[r] = fast_exp2(__builtin_fmaf(st[r], p.scale_log2e, -mn));
+    };
+    auto pack_step = [&](const float (&st)[32], int s) {  // registers 8s..8s+7 are k-step s; element j is key 16s + 8(j>>2) + 4h + (j&3)
+        return make_uint4(pack_bf16(st[8 * s + 0], st[8 * s + 1]), pack_bf16(st[8 * s + 2], st[8 * s + 3]),
+                          pack_bf16(st[8 * s + 4], st[8 * s + 5]), pack_bf16(st[8 * s + 6], st[8 * s + 7]));
+    };
+    // row sum of the ROUNDED probabilities (the values the matrix product uses), two per v_dot2c
+    auto sum_step = [&](const uint4& f, float acc) {
         constexpr uint32_t kOnes = 0x3F803F80u;
-        float ps0 = dot2_bf16(pf[0].x, kOnes, 0.f), ps1 = dot2_bf16(pf[1].x, kOnes, 0.f);
-        ps0 = dot2_bf16(pf[0].y, kOnes, ps0), ps1 = dot2_bf16(pf[1].y, kOnes, ps1);
-        ps0 = dot2_bf16(pf[0].z, kOnes, ps0), ps1 = dot2_bf16(pf[1].z, kOnes, ps1);
-        ps0 = dot2_bf16(pf[0].w, kOnes, ps0), ps1 = dot2_bf16(pf[1].w, kOnes, ps1);
-        l = l * alpha + (ps0 + ps1);  // per-lane partial sum; halves are added after the loop
+        acc = dot2_bf16(f.x, kOnes, acc);
+        acc = dot2_bf16(f.y, kOnes, acc);
+        acc = dot2_bf16(f.z, kOnes, acc);
+        return dot2_bf16(f.w, kOnes, acc);
+    };
+    auto sum_tile = [&]() { return sum_step(pf[0], sum_step(pf[2], 0.f)) + sum_step(pf[1], sum_step(pf[3], 0.f)); };
+    auto rescale_o = [&](float alpha) {
         if (!__all(alpha == 1.0f)) {  // the running max settles after a few tiles: usually nothing to rescale
 #pragma unroll
             for (int d = 0; d < 4; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
         }
-        // ---- O^T += V^T . P^T ----
+    };
+    // whole softmax of one tile, no overlap (first tile and tiles on the diagonal); returns alpha
+    auto softmax_tile = [&](const f32x16_t& s0, const f32x16_t& s1, int k0, bool masked) {
+        float st[32];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
+        for (int r = 0; r < 16; ++r) st[r] = s0[r], st[16 + r] = s1[r];
+        if (masked) mask_scores(st, k0);
+        const float mn = fmaxf(m, row_max(st) * p.scale_log2e);
+        const float alpha = fast_exp2(m - mn);
+        m = mn;
+        exp_range(st, 0, 32, mn);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const char* va = v_lane + (sb * 32 + 16 * s) * kVRow + d * 64;
-                const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(va));
-                const short4_t hi =
-                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(va + 8 * kVRow));
-                typedef __attribute__((ext_vector_type(8))) short short8_t;
-                short8_t a;
-                a.lo = lo;
-                a.hi = hi;
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), as_bf16x8(pf[s]), o[d], 0, 0, 0);
-            }
-        }
+        for (int s = 0; s < 4; ++s) pf[s] = pack_step(st, s);
+        return alpha;  // the row sum of the tile is added when its O^T update is issued
     };
 
-    // staging: thread owns 16-byte chunk c16 of keys skey, skey+16, skey+32, skey+48 of a tile
+    // staging: thread owns 16-byte chunk c16 of keys skey + i * KSTEP of a tile
     const int c16 = tid & 15;
     const int skey = tid >> 4;
     const uint16_t* kcol = p.kc + hk * kHD + c16 * 8;
     const uint16_t* vcol = p.vc + hk * kHD + c16 * 8;
-    StageSlots slots = stage_slots(r2t_row, 0, skey, kv_len);
-    StageRegs stg = stage_load(kcol, vcol, p.cache_stride, slots);
-    slots = stage_slots(r2t_row, min(1, nkt - 1), skey, kv_len);
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();  // every wave is done reading the previous tile
-        stage_write(lds_k, lds_v, skey, c16, stg);
-        __syncthreads();
-        stg = stage_load(kcol, vcol, p.cache_stride, slots);  // tile kt+1 (last tile: harmless re-read)
-        slots = stage_slots(r2t_row, min(kt + 2, nkt - 1), skey, kv_len);
+    StageSlots<KPT> slots = stage_slots<KPT, KSTEP>(r2t_row, 0, skey, kv_len);
+    StageRegs<KPT> stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
+    slots = stage_slots<KPT, KSTEP>(r2t_row, min(1, nkt - 1), skey, kv_len);
+    stage_write<KPT, KSTEP>(lds, skey, c16, stg);
+    stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);  // tile 1 (single tile: harmless re-read)
+    slots = stage_slots<KPT, KSTEP>(r2t_row, min(2, nkt - 1), skey, kv_len);
+    __syncthreads();
+    if (my_nkt > 0) {
+        f32x16_t s0, s1;
+        qk_tile(0, s0, s1);
+        softmax_tile(s0, s1, 0, full_nkt == 0);
+    }
 
-        const int k0 = kt * kBN;
-        if (k0 + kBN - 1 <= prefix + row0) {  // wave-uniform: every key of the tile is visible to every row
-#pragma unroll 1  // one copy of the block: unrolled, the two copies' operand reads interleave and spill
-            for (int sb = 0; sb < 2; ++sb) block(BoolTag<false>{}, sb, k0 + sb * 32);
-        } else {
+    int cur = 0, nxt = kTileBytes;  // LDS offsets of tiles t and t+1 in the ring
+    auto advance_ring = [&]() {
+        cur = nxt;
+        nxt = (nxt == (kStages - 1) * kTileBytes) ? 0 : nxt + kTileBytes;
+    };
+    // Every iteration of either loop below: stage tile t+1 into the ring, one barrier, then the pending
+    // factor and row sum of tile t (whose P^T is in pf), then the matrix work.  Waves of one work group
+    // leave the first loop at different t; both loops have one barrier per iteration, so the counts agree.
+    int t = 0;
+    // ---- steady state: tile t+1 is visible to every row of the wave ----
+    for (; t + 1 < full_nkt; ++t) {
+        // ring slot of tile t+1 was last read for tile t-2; every wave passed the barrier of iteration t-1 after that
+        stage_write<KPT, KSTEP>(lds + nxt, skey, c16, stg);
+        stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);  // tile t+2 (last tiles: harmless re-read)
+        slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + 3, nkt - 1), skey, kv_len);
+        __syncthreads();
+        rescale_o(alpha_pend);  // a branch of its own, ahead of the block below, so that nothing of that block sinks behind it
+
+        // S^T of tile t+1 (reads two k-steps ahead of the matrix instructions), the row sum of tile t beside it
+        f32x16_t s0, s1;
+        short8_t vf[4], vg[4];
+        qk_tile(nxt, s0, s1);
+        v_step(cur, 0, vf);
+        l = l * alpha_pend + sum_tile();
+        __builtin_amdgcn_sched_group_barrier(SG_DSREAD, 6, 0);
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
-                const int kb = k0 + sb * 32;            // first key position of this 32-key block
-                if (kb > prefix + row0 + 31) continue;  // wave-uniform: block entirely above the diagonal
-                block(BoolTag<true>{}, sb, kb);
-            }
+        for (int i = 0; i < 10; ++i) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_DSREAD, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_VALU, 2, 0);
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_DSREAD, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_VALU, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float st[32];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = s0[r], st[16 + r] = s1[r];
+        // O^T of tile t, k-step by k-step (the consumed P^T registers free up for the new ones), with the
+        // softmax of tile t+1 in its shadow.  k-step 0 beside the row max (asm max3: ordered by hand).
+        v_step(cur, 1, vg);
+        float mx = max3_raw(st[0], st[1], st[2]);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf[d]), as_bf16x8(pf[0]), o[d], 0, 0, 0);
+#pragma unroll
+            for (int r = 3 + 8 * d; r < 11 + 8 * d && r < 31; r += 2) mx = max3_raw(mx, st[r], st[r + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float mn = fmaxf(m, max_with_lane_xor32(fmaxf(mx, st[31])) * p.scale_log2e);
+        alpha_pend = fast_exp2(m - mn);
+        m = mn;
+        // k-step 1 beside the first 12 exps; P^T of k-step 0 is consumed, its registers take the new one
+        v_step(cur, 2, vf);
+        pv_step(1, vg);
+        exp_range(st, 0, 12, mn);
+        pf[0] = pack_step(st, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_VALU, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_TRANS, 3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // k-step 2 beside the next 12
+        v_step(cur, 3, vg);
+        pv_step(2, vf);
+        exp_range(st, 12, 24, mn);
+        pf[1] = pack_step(st, 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_VALU, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_TRANS, 3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // k-step 3 beside the last 8
+        pv_step(3, vg);
+        exp_range(st, 24, 32, mn);
+        pf[2] = pack_step(st, 2);
+        const uint4 n3 = pack_step(st, 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_VALU, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_TRANS, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pf[3] = n3;
+        advance_ring();
+    }
+    // ---- the diagonal tiles, then the tiles only other waves of the work group still need ----
+    for (; t < nkt; ++t) {
+        if (t + 1 < nkt) {
+            stage_write<KPT, KSTEP>(lds + nxt, skey, c16, stg);
+            stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
+            slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + 3, nkt - 1), skey, kv_len);
+        }
+        __syncthreads();
+        if (t < my_nkt) {
+            rescale_o(alpha_pend);
+            l = l * alpha_pend + sum_tile();
+            alpha_pend = 1.0f;
+            f32x16_t s0, s1;
+            const bool more = t + 1 < my_nkt;
+            if (more) qk_tile(nxt, s0, s1);
+            short8_t vf[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                v_frags(cur, d, vf);
+                pv_block(d, vf);
+            }
+            if (more) alpha_pend = softmax_tile(s0, s1, (t + 1) * kBN, true);
+        }
+        advance_ring();
     }
 
     l += __shfl_xor(l, 32);
@@ -278,6 +431,21 @@ __global__ __launch_bounds__(256, 2) void paged_extend_kernel(ExtendParams p) {
             *reinterpret_cast<uint2*>(op + col) = make_uint2(pack_bf16(o[d][4 * rr] * inv, o[d][4 * rr + 1] * inv),
                                                             pack_bf16(o[d][4 * rr + 2] * inv, o[d][4 * rr + 3] * inv));
         }
+}
+
+template <int NH>
+static int launch_extend(const ExtendParams& p, int64_t blocks, hipStream_t stream) {
+    static bool configured = false;  // the ring is larger than the 64 KiB a kernel gets by default
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(paged_extend_kernel<NH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kExtendLds) != hipSuccess) {
+            set_error("msgl_paged_extend: cannot reserve %d bytes of LDS", kExtendLds);
+            return MSGL_E_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(paged_extend_kernel<NH>, dim3((unsigned)blocks), dim3(256 * NH), kExtendLds, stream, p);
+    return check_launch("paged_extend_kernel");
 }
 
 }  // namespace msgl
@@ -321,8 +489,8 @@ extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_
     p.hkv = Hkv;
     p.group = Hq / Hkv;
     p.scale_log2e = scale * 1.4426950408889634f;
-    const int64_t gx = (int64_t)bs * p.tiles_per_req * Hq;
+    const int nh = (p.group % 2 == 0) ? 2 : 1;  // query heads per work group
+    const int64_t gx = (int64_t)bs * p.tiles_per_req * (Hq / nh);
     MSGL_REQUIRE(gx <= 0x7fffffff, "msgl_paged_extend: grid too large");
-    hipLaunchKernelGGL(paged_extend_kernel, dim3((unsigned)gx), dim3(256), 0, static_cast<hipStream_t>(stream), p);
-    return check_launch("paged_extend_kernel");
+    return nh == 2 ? launch_extend<2>(p, gx, static_cast<hipStream_t>(stream)) : launch_extend<1>(p, gx, static_cast<hipStream_t>(stream));
 }
