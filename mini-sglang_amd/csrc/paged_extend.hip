@@ -120,7 +120,7 @@ __device__ __forceinline__ void stage_write(char* tile, int skey, int c16, const
     }
 }
 
-constexpr int SG_VALU = 0x002, SG_MFMA = 0x008, SG_DSREAD = 0x100, SG_TRANS = 0x400;
+constexpr int SG_VALU = 0x002, SG_MFMA = 0x008, SG_VMEMREAD = 0x020, SG_DSREAD = 0x100, SG_DSWRITE = 0x200, SG_TRANS = 0x400;
 
 template <int NH>
 __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams p) {
@@ -286,12 +286,16 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
     const int skey = tid >> 4;
     const uint16_t* kcol = p.kc + hk * kHD + c16 * 8;
     const uint16_t* vcol = p.vc + hk * kHD + c16 * 8;
+    // tiles 0 and 1 go to ring slots 0 and 1 before the first barrier, tile 2 waits in registers
     StageSlots<KPT> slots = stage_slots<KPT, KSTEP>(r2t_row, 0, skey, kv_len);
     StageRegs<KPT> stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
     slots = stage_slots<KPT, KSTEP>(r2t_row, min(1, nkt - 1), skey, kv_len);
     stage_write<KPT, KSTEP>(lds, skey, c16, stg);
-    stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);  // tile 1 (single tile: harmless re-read)
+    stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);  // (past the last tile: harmless re-read of it)
     slots = stage_slots<KPT, KSTEP>(r2t_row, min(2, nkt - 1), skey, kv_len);
+    stage_write<KPT, KSTEP>(lds + kTileBytes, skey, c16, stg);
+    stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
+    slots = stage_slots<KPT, KSTEP>(r2t_row, min(3, nkt - 1), skey, kv_len);
     __syncthreads();
     if (my_nkt > 0) {
         f32x16_t s0, s1;
@@ -299,23 +303,28 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
         softmax_tile(s0, s1, 0, full_nkt == 0);
     }
 
-    int cur = 0, nxt = kTileBytes;  // LDS offsets of tiles t and t+1 in the ring
+    int cur = 0, nxt = kTileBytes, nn = 2 * kTileBytes;  // LDS offsets of tiles t, t+1, t+2 in the ring
     auto advance_ring = [&]() {
-        cur = nxt;
-        nxt = (nxt == (kStages - 1) * kTileBytes) ? 0 : nxt + kTileBytes;
+        const int c = cur;
+        cur = nxt, nxt = nn, nn = c;
     };
-    // Every iteration of either loop below: stage tile t+1 into the ring, one barrier, then the pending
-    // factor and row sum of tile t (whose P^T is in pf), then the matrix work.  Waves of one work group
-    // leave the first loop at different t; both loops have one barrier per iteration, so the counts agree.
+    // Every iteration of either loop below: one barrier (tile t+1, written during iteration t-1, becomes
+    // visible and the ring slot tile t-1 was read from becomes free); tile t+2 goes from registers into that
+    // slot and the loads of tile t+3 are issued, all beside the matrix work; the pending factor and row sum
+    // of tile t (whose P^T is in pf) are applied; then the matrix work.  Waves of one work group leave the
+    // first loop at different t; both loops have one barrier per iteration, so the counts agree.
     int t = 0;
     // ---- steady state: tile t+1 is visible to every row of the wave ----
     for (; t + 1 < full_nkt; ++t) {
-        // ring slot of tile t+1 was last read for tile t-2; every wave passed the barrier of iteration t-1 after that
-        stage_write<KPT, KSTEP>(lds + nxt, skey, c16, stg);
-        stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);  // tile t+2 (last tiles: harmless re-read)
-        slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + 3, nkt - 1), skey, kv_len);
+#ifndef MSGL_EXP_NOBARRIER
         __syncthreads();
+#endif
         rescale_o(alpha_pend);  // a branch of its own, ahead of the block below, so that nothing of that block sinks behind it
+#ifndef MSGL_EXP_NOSTAGE
+        stage_write<KPT, KSTEP>(lds + nn, skey, c16, stg);
+        stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);  // tile t+3
+        slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + 4, nkt - 1), skey, kv_len);
+#endif
 
         // S^T of tile t+1 (reads two k-steps ahead of the matrix instructions), the row sum of tile t beside it
         f32x16_t s0, s1;
@@ -325,16 +334,24 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
         l = l * alpha_pend + sum_tile();
         __builtin_amdgcn_sched_group_barrier(SG_DSREAD, 6, 0);
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
+        for (int i = 0; i < 2 * KPT; ++i) {  // the ring-slot writes of tile t+2 ...
             __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
             __builtin_amdgcn_sched_group_barrier(SG_DSREAD, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(SG_VALU, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_VALU, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_DSWRITE, 1, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 2 * KPT; i < 10; ++i) {  // ... then the loads of tile t+3
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_DSREAD, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_VALU, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_VMEMREAD, 1, 0);
+        }
+#pragma unroll
+        for (int i = 10; i < 14; ++i) {
             __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
             __builtin_amdgcn_sched_group_barrier(SG_DSREAD, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(SG_VALU, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_VALU, 3, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         float st[32];
@@ -395,12 +412,10 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
     }
     // ---- the diagonal tiles, then the tiles only other waves of the work group still need ----
     for (; t < nkt; ++t) {
-        if (t + 1 < nkt) {
-            stage_write<KPT, KSTEP>(lds + nxt, skey, c16, stg);
-            stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
-            slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + 3, nkt - 1), skey, kv_len);
-        }
         __syncthreads();
+        stage_write<KPT, KSTEP>(lds + nn, skey, c16, stg);  // past the last tile: a copy of it into a free slot
+        stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
+        slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + 4, nkt - 1), skey, kv_len);
         if (t < my_nkt) {
             rescale_o(alpha_pend);
             l = l * alpha_pend + sum_tile();
