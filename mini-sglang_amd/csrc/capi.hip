@@ -21,6 +21,19 @@ int check_launch(const char* what) {
     return MSGL_E_LAUNCH;
 }
 
+// Compute units of the current device (cached per device id; 256 if the query fails).
+int device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 }  // namespace msgl
 
 extern "C" int msgl_abi_version(void) { return 2; }

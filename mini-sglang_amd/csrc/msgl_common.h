@@ -12,6 +12,7 @@ namespace msgl {
 // ---- host side -------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+int device_cus();
 
 #define MSGL_REQUIRE(cond, ...)            \
     do {                                   \

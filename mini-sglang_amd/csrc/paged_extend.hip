@@ -17,6 +17,8 @@
 // The loop is software pipelined inside each wave: iteration t issues S^T of tile t+1, then
 // the 16 matrix instructions of O^T for tile t with the softmax arithmetic of tile t+1
 // placed between them, so the vector and matrix pipes run side by side.
+#include <stdlib.h>
+
 #include "msgl_common.h"
 
 namespace msgl {
@@ -504,7 +506,10 @@ extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_
     p.hkv = Hkv;
     p.group = Hq / Hkv;
     p.scale_log2e = scale * 1.4426950408889634f;
-    const int nh = (p.group % 2 == 0) ? 2 : 1;  // query heads per work group
+    // query heads per work group: 2 share the staged K/V tile; 1 when that would leave compute units without a block
+    int nh = (p.group % 2 == 0) ? 2 : 1;
+    if (const char* e = getenv("MSGL_EXTEND_NH")) nh = (atoi(e) == 2 && p.group % 2 == 0) ? 2 : 1;
+    else if (nh == 2 && (int64_t)bs * p.tiles_per_req * (Hq / 2) <= device_cus()) nh = 1;
     const int64_t gx = (int64_t)bs * p.tiles_per_req * (Hq / nh);
     MSGL_REQUIRE(gx <= 0x7fffffff, "msgl_paged_extend: grid too large");
     return nh == 2 ? launch_extend<2>(p, gx, static_cast<hipStream_t>(stream)) : launch_extend<1>(p, gx, static_cast<hipStream_t>(stream));

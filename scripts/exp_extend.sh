@@ -1,8 +1,6 @@
-# timing experiments: variant libraries under build/<name>/ against the same driver
-for v in BASE NOBARRIER NOSTAGE BOTH; do
-  for rep in 1 2; do
-    if [ $v = BASE ]; then timeout -k 10 60 ./tools/extend_bench --bs 2 --sq 8192 --steps 20 | cut -c80-140
-    else LD_LIBRARY_PATH=build/$v timeout -k 10 60 ./tools/extend_bench --bs 2 --sq 8192 --steps 20 | cut -c80-140; fi
-    echo "  ^ $v"
+# work-group shape experiments on small grids (MSGL_EXTEND_NH overrides the heuristic)
+for args in "--bs 1 --sq 4096 --hq 8 --hkv 1 --ps 64" "--bs 1 --sq 2048 --hq 32 --hkv 8" "--bs 4 --sq 1024 --hq 32 --hkv 8" "--bs 2 --sq 8192 --hq 32 --hkv 8"; do
+  for nh in 1 2; do
+    MSGL_EXTEND_NH=$nh timeout -k 10 60 ./tools/extend_bench $args --steps 20 | cut -c1-130; echo "  ^ NH=$nh"
   done
 done
