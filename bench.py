@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-e2e", action="store_true", help="skip the full-model decode tok/s measurement")
+    ap.add_argument("--no-extend", action="store_true", help="skip the prefill-attention TFLOP/s measurement")
     ap.add_argument("--e2e-ctx", type=int, default=0, help="0 = 8192 if the whole-model KV fits in HBM, else the largest power of two that does")
     ap.add_argument("--e2e-steps", type=int, default=16)
     ap.add_argument("--e2e-eager", action="store_true", help="do not capture decode steps in hipGraphs")
@@ -181,6 +182,8 @@ def main():
         result["roofline"]["traffic_source"] = "profiles/r01_decode_bs256_ctx8192.md"
     del pools, qs, ws, out
     torch.cuda.empty_cache()
+    if not args.no_extend:
+        result["extend"] = extend_attention(args, world, rank)
     if not args.no_e2e:
         result["decode_e2e"] = decode_e2e(args, world, rank, barrier)
     if rank == 0:
@@ -189,6 +192,50 @@ def main():
         import torch.distributed as dist
 
         dist.destroy_process_group()
+
+
+def extend_attention(args, world, rank):
+    """Prefill attention of one transformer layer (the MFMA-bound half of the path): one 16384-token prompt, the
+    reference's default prefill budget, no cached prefix, same heads and page size as the headline shape.  Reported
+    beside the headline number, never as `value`: causal flops / HIP-event time per launch on this rank."""
+    from mini_sglang_amd import ops
+    from mini_sglang_amd.runtime import synth, workload
+
+    try:
+        D, ps, Sq = 128, args.page_size, 16384
+        Hq, Hkv = args.hq // world, args.hkv // world
+        pages = -(-Sq // ps) + 8
+        pt = workload.make_page_table([Sq], ps, pages, seed=5, scatter=True)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        kv = synth.normal(((pages + 1) * ps, 2, Hkv, D), 31 + rank, device=dev)
+        q = synth.normal((Sq, Hq, D), 32 + rank, device=dev)
+        out = torch.empty_like(q)
+        r2t = pt.req_to_token.to(dev)
+        idx = torch.zeros(1, dtype=torch.int32, device=dev)
+        cu = torch.tensor([0, Sq], dtype=torch.int32, device=dev)
+        pre = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def f():
+            ops.paged_extend(q, kv[:, 0], kv[:, 1], r2t, idx, cu, pre, Sq, D ** -0.5, ps, out=out)
+
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        steps = 10
+        e0.record()
+        for _ in range(steps):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        flops = 4 * Hq * D * Sq * (Sq + 1) / 2
+        tf = flops / (ms * 1e-3) / 1e12
+        return {"workload": f"one {Sq}-token prompt, {Hq} q / {Hkv} kv heads per GPU, page_size {ps}", "ms_per_launch": round(ms, 4),
+                "TFLOPs_per_gpu": round(tf, 1),
+                "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4)}}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def decode_e2e(args, world, rank, barrier):
