@@ -179,6 +179,33 @@ int msgl_qknorm_rope_store(void* qkv, int64_t qkv_stride, const void* q_norm_w, 
 int msgl_argmax(const void* logits, int64_t row_stride, int elem_bytes, int32_t* out,
                 int bs, int vocab, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Decode-step preparation on the device.  Replaces BatchInfo.prepare_for_decode
+ * (mini_sglang/managers/batch_info.py:247-302) together with the allocator call inside it
+ * (PageAllocator.alloc takes pages from the FRONT of the free list,
+ * mini_sglang/mem_cache/token2kv.py:186-196), so that decode steps can follow each other
+ * on the GPU without the host:
+ *   old = seq_lens[i];  positions[i] = old;  seq_lens[i] = old + 1;
+ *   slot = (page_size == 1 || old % page_size == 0)
+ *            ? free_pages[free_range[0] + (number of requests j < i that also take a page)] * page_size
+ *            : last_slots[i] + 1;
+ *   out_cache_loc[i] = last_slots[i] = req_to_token[req_pool_indices[i], old] = slot;
+ *   input_ids[i] = next_tokens[i]            (both NULL: the caller sets input_ids itself)
+ *   free_range[0] += number of pages taken.
+ * free_pages: int32 [free_capacity], the allocator's free list in its order; free_range: device
+ * int32 [2] = {index of the first page not yet handed out, end of the valid entries}: both live on
+ * the device so that a captured launch keeps working when the host rewrites the list between
+ * steps.  last_slots: int32 [bs], slot of each request's last stored token.  All-or-nothing: if the free list cannot serve the step
+ * (*status = 1) or a request already fills its table row of max_ctx entries (*status = 2)
+ * nothing is written; *status is left untouched on success (the caller zeroes it once).
+ * ------------------------------------------------------------------------- */
+int msgl_prepare_decode(const int32_t* req_pool_indices, int32_t* seq_lens, int32_t* last_slots,
+                        const int32_t* free_pages, int32_t free_capacity, int32_t* free_range,
+                        int32_t* req_to_token, int64_t r2t_stride, int32_t max_ctx,
+                        int32_t* positions, int32_t* out_cache_loc,
+                        const int32_t* next_tokens, int32_t* input_ids,
+                        int32_t* status, int bs, int page_size, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -280,3 +280,30 @@ def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
     _dev_i32(out, "out")
     _check(_lib.msgl_argmax(logits.data_ptr(), rs, logits.element_size(), out.data_ptr(), bs, vocab, _stream()))
     return out
+
+
+def prepare_decode(req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, last_slots: torch.Tensor, free_pages: torch.Tensor,
+                   free_range: torch.Tensor, req_to_token: torch.Tensor, positions: torch.Tensor, out_cache_loc: torch.Tensor,
+                   status: torch.Tensor, page_size: int, next_tokens: Optional[torch.Tensor] = None,
+                   input_ids: Optional[torch.Tensor] = None) -> None:
+    """One decode step's batch preparation on the device (see msgl_prepare_decode): advances ``seq_lens``,
+    ``last_slots``, ``free_range[0]`` and writes ``positions``, ``out_cache_loc``, the page table and (optionally)
+    ``input_ids`` in place.  ``status`` (int32[1]) becomes non-zero if the step was refused."""
+    bs = req_pool_indices.numel()
+    for name, t, n in (("req_pool_indices", req_pool_indices, bs), ("seq_lens", seq_lens, bs), ("last_slots", last_slots, bs),
+                       ("positions", positions, bs), ("out_cache_loc", out_cache_loc, bs), ("free_range", free_range, 2),
+                       ("status", status, 1), ("free_pages", free_pages, free_pages.numel())):
+        _dev_i32(t, name)
+        _need(t.numel() == n, f"{name}: expected {n} elements, got {t.numel()}")
+    _need(req_to_token.is_cuda and req_to_token.dtype == torch.int32 and req_to_token.dim() == 2 and req_to_token.stride(1) == 1,
+          "req_to_token must be an int32 [rows, max_ctx] GPU tensor with contiguous rows")
+    _need((next_tokens is None) == (input_ids is None), "next_tokens and input_ids go together")
+    if next_tokens is not None:
+        _dev_i32(next_tokens, "next_tokens")
+        _dev_i32(input_ids, "input_ids")
+        _need(next_tokens.numel() == bs and input_ids.numel() == bs, "next_tokens / input_ids: one entry per request")
+    _check(_lib.msgl_prepare_decode(
+        req_pool_indices.data_ptr(), seq_lens.data_ptr(), last_slots.data_ptr(), free_pages.data_ptr(), free_pages.numel(),
+        free_range.data_ptr(), req_to_token.data_ptr(), req_to_token.stride(0), req_to_token.shape[1], positions.data_ptr(),
+        out_cache_loc.data_ptr(), next_tokens.data_ptr() if next_tokens is not None else None,
+        input_ids.data_ptr() if input_ids is not None else None, status.data_ptr(), bs, page_size, _stream()))

@@ -161,6 +161,32 @@ def argmax_ref(logits: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- fp64 ground truth (tests only)
+def prepare_decode_ref(req_pool_indices, seq_lens, last_slots, free_pages, free_head: int, req_to_token: torch.Tensor,
+                       page_size: int):
+    """One decode step's batch preparation, request by request, as the reference does it
+    (mini_sglang/managers/batch_info.py:247-302; page order: PageAllocator.alloc takes from the front of the
+    free list, mini_sglang/mem_cache/token2kv.py:186-196).  Plain Python lists / ints in, written in place
+    (``seq_lens``, ``last_slots``, ``req_to_token``); returns (positions, out_cache_loc, new free_head), or
+    raises RuntimeError like the allocator when the free list runs out (nothing is modified then)."""
+    ps = page_size
+    need = sum(1 for old in seq_lens if ps == 1 or old % ps == 0)
+    if need > len(free_pages) - free_head:
+        raise RuntimeError(f"Not enough free pages available. need {need}, free {len(free_pages) - free_head}")
+    positions, out_loc = [], []
+    for i, old in enumerate(seq_lens):
+        if ps == 1 or old % ps == 0:          # batch_info.py:277-283: a fresh page, first slot
+            slot = int(free_pages[free_head]) * ps
+            free_head += 1
+        else:                                 # batch_info.py:286-291: the slot after the previous token's
+            slot = int(last_slots[i]) + 1
+        positions.append(int(old))
+        out_loc.append(slot)
+        req_to_token[int(req_pool_indices[i]), int(old)] = slot   # batch_info.py:298-300
+        seq_lens[i] = int(old) + 1            # batch_info.py:262-263
+        last_slots[i] = slot
+    return positions, out_loc, free_head
+
+
 def paged_attention_fp64(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, tok: torch.Tensor, scale: float,
                          q_positions: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Exact softmax(q K^T) V in float64 for ONE request: q [Sq, Hq, D], tok = its slot list [S].

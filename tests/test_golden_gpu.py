@@ -120,3 +120,38 @@ def test_e2e_hip_vs_oracle_on_same_device():
     assert torch.equal(hip["tokens"], ref["tokens"])
     assert (hip["logits_slices"].float() - ref["logits_slices"].float()).abs().max().item() <= 2e-2
     assert torch.equal(hip["req_to_token_rows"], ref["req_to_token_rows"])
+
+
+@pytest.mark.parametrize("ps", [1, 16])
+def test_device_chained_decode_equals_host_prepared_steps(ps):
+    """k decode steps chained on the GPU (msgl_prepare_decode -> forward -> argmax in one hipGraph, no host work
+    between steps) leave the same tokens, page table, last slots and allocator state as k steps prepared on the
+    host by BatchInfo.prepare_for_decode."""
+    from mini_sglang_amd.runtime import decode_loop
+    from mini_sglang_amd.runtime.device_decode import DeviceDecodeLoop
+    from mini_sglang_amd.runtime.qwen3 import Qwen3Config
+
+    def build():
+        torch.manual_seed(1234)  # the harness fills the K/V pools from torch's generator: same contexts in both runs
+        cfg = Qwen3Config(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                          intermediate_size=512, vocab_size=2048, max_position_embeddings=1024, tie_word_embeddings=False)
+        return decode_loop.build_decode_state(cfg, 5, 0, ps, 64, use_graph=False, seed=3, seq_lens=[15, 16, 33, 200, 1])
+
+    steps = 24
+    mr_a, batch_a = build()
+    decode_loop.decode_steps(mr_a, batch_a, steps)
+    mr_b, batch_b = build()
+    loop = DeviceDecodeLoop(mr_b, batch_b, max_steps=32)
+    loop.run(10)
+    first = loop.sync_host()
+    loop.run(steps - 10)
+    second = loop.sync_host()
+    assert all(len(a) == 10 for a in first) and all(len(a) == steps - 10 for a in second)
+    for ra, rb in zip(batch_a.reqs, batch_b.reqs):
+        assert ra.token_ids == rb.token_ids
+        assert ra.last_slot == rb.last_slot
+    assert torch.equal(batch_a.seq_lens_cpu, batch_b.seq_lens_cpu)
+    assert torch.equal(mr_a.page_allocator.free_page, mr_b.page_allocator.free_page)
+    for ra, rb in zip(batch_a.reqs, batch_b.reqs):
+        n = len(ra.token_ids)
+        assert torch.equal(mr_a.req_to_token_pool.req_to_token[ra.req_pool_idx, :n], mr_b.req_to_token_pool.req_to_token[rb.req_pool_idx, :n])

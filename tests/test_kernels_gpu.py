@@ -340,3 +340,58 @@ def test_argmax():
     for t in (logits, logits.float()):
         got = ops.argmax(t.to(DEV)).cpu()
         assert torch.equal(got, orc.argmax_ref(t)), (got, orc.argmax_ref(t))
+
+
+# ------------------------------------------------------------------------------------------------ batch preparation
+def _prepare_case(bs, ps, seed, max_ctx=512):
+    synth, _ = _synth()
+    lens = (synth.uniform_int(bs, seed, 1, max_ctx - 40)).tolist()
+    if bs >= 4:
+        lens[0], lens[1], lens[2], lens[3] = ps, ps - 1 if ps > 1 else 1, 2 * ps, 1  # page boundaries in the first steps
+    rows = synth.permutation(bs + 5, seed + 1)[:bs].tolist()                        # table rows in no particular order
+    total_pages = bs * (max_ctx // ps + 2)
+    free_pages = (synth.permutation(total_pages, seed + 2) + 1).tolist()            # a free list in allocator order
+    last = (synth.uniform_int(bs, seed + 3, ps, ps * total_pages)).tolist()
+    r2t = torch.zeros((bs + 5, max_ctx), dtype=torch.int32)
+    return lens, rows, free_pages, last, r2t
+
+
+@pytest.mark.parametrize("bs,ps", [(1, 1), (3, 16), (300, 1), (300, 16), (1500, 16), (2500, 64)])
+def test_prepare_decode_matches_oracle(bs, ps):
+    ops = _ops()
+    lens, rows, free_pages, last, r2t = _prepare_case(bs, ps, 11 + bs + ps)
+    d = lambda x: torch.tensor(x, dtype=torch.int32, device=DEV)
+    seq_d, rows_d, free_d, last_d, r2t_d = d(lens), d(rows), d(free_pages), d(last), r2t.to(DEV)
+    head_d, status = d([7, len(free_pages)]), d([0])
+    pos_d, loc_d = torch.empty(bs, dtype=torch.int32, device=DEV), torch.empty(bs, dtype=torch.int32, device=DEV)
+    toks = d(list(range(100, 100 + bs)))
+    ids_d = torch.empty(bs, dtype=torch.int32, device=DEV)
+    head = 7
+    for step in range(20):  # 20 steps: every request with page_size 16 crosses a page boundary at least once
+        positions, loc, head = orc.prepare_decode_ref(rows, lens, last, free_pages, head, r2t, ps)
+        ops.prepare_decode(rows_d, seq_d, last_d, free_d, head_d, r2t_d, pos_d, loc_d, status, ps, next_tokens=toks, input_ids=ids_d)
+        assert pos_d.tolist() == positions and loc_d.tolist() == loc, f"step {step}"
+    assert status.item() == 0 and head_d.tolist() == [head, len(free_pages)]
+    assert seq_d.tolist() == lens and last_d.tolist() == last
+    assert torch.equal(r2t_d.cpu(), r2t)
+    assert torch.equal(ids_d, toks)
+
+
+def test_prepare_decode_refuses_as_a_whole():
+    ops = _ops()
+    d = lambda x: torch.tensor(x, dtype=torch.int32, device=DEV)
+    # three requests, two of them need a page, one page left: refused, nothing written
+    seq, rows, last = d([16, 5, 32]), d([0, 1, 2]), d([31, 100, 63])
+    free, head, status = d([9, 4]), d([1, 2]), d([0])
+    r2t = torch.full((3, 64), -1, dtype=torch.int32, device=DEV)
+    pos, loc = d([-1, -1, -1]), d([-1, -1, -1])
+    ops.prepare_decode(rows, seq, last, free, head, r2t, pos, loc, status, 16)
+    assert status.item() == 1 and head.tolist() == [1, 2]
+    assert seq.tolist() == [16, 5, 32] and pos.tolist() == [-1] * 3 and loc.tolist() == [-1] * 3 and (r2t == -1).all()
+    with pytest.raises(RuntimeError):
+        orc.prepare_decode_ref([0, 1, 2], [16, 5, 32], [31, 100, 63], [9, 4], 1, torch.zeros((3, 64), dtype=torch.int32), 16)
+    # a request that already fills its table row: refused with status 2
+    status.zero_()
+    seq2 = d([64, 5, 3])
+    ops.prepare_decode(rows, seq2, last, d([9, 4, 5]), d([0, 3]), r2t, pos, loc, status, 16)
+    assert status.item() == 2 and seq2.tolist() == [64, 5, 3] and (r2t == -1).all()

@@ -58,3 +58,29 @@ def test_e2e_fixture_matches_oracle_harness(name):
     got = gc.run_e2e(name, "cpu", layers=mo, backend_factory=mo.OracleAttnBackend)
     for key in ("tokens", "margins", "top1_logits", "logits_slices", "out_cache_loc_first", "out_cache_loc_decode", "req_to_token_rows"):
         assert torch.equal(got[key], fx[key]), key
+
+
+@pytest.mark.parametrize("name", ["tiny_ps1", "tiny_ps16", "qwen3_0.6b_ps1"])
+def test_prepare_decode_oracle_matches_reference_slots(name):
+    """The decode-step preparation restated in the oracle reproduces the slots the REFERENCE assigned in its own
+    run of the case (fixture fields out_cache_loc_first / out_cache_loc_decode / req_to_token_rows)."""
+    fx = gc.load(f"e2e_{name}.pt")
+    _, ps, (_, plens), _, _, _, _, _ = gg.E2E_CASES[name]
+    first = fx["out_cache_loc_first"].tolist()
+    pages = 1024 // ps
+    used = len(first) if ps == 1 else sum(-(-n // ps) for n in plens)   # pages the extend step took, in order
+    free_pages = list(range(1, pages + 1))
+    head = used
+    r2t = torch.zeros((len(plens), 2048), dtype=torch.int32)
+    seq, last, pos = list(plens), [], 0
+    for i, n in enumerate(plens):
+        r2t[i, :n] = torch.tensor(first[pos: pos + n], dtype=torch.int32)
+        pos += n
+        last.append(first[pos - 1])
+    rows = list(range(len(plens)))
+    for step, want in enumerate(fx["out_cache_loc_decode"].tolist()):
+        positions, loc, head = orc.prepare_decode_ref(rows, seq, last, free_pages, head, r2t, ps)
+        assert loc == want, f"step {step}"
+        assert positions == [s - 1 for s in seq]
+    got_rows = torch.cat([r2t[i, : seq[i]] for i in rows])
+    assert torch.equal(got_rows, fx["req_to_token_rows"].to(torch.int32))
