@@ -259,14 +259,14 @@ def decode_e2e(args, world, rank, barrier):
         info = {"model": "Qwen3-8B shape, random weights", "batch": bs, "ctx": ctx, "page_size": ps, "tp": world}
         use_graph = not args.e2e_eager
         try:
-            mr, batch = decode_loop.build_decode_state(cfg, bs, ctx, ps, args.e2e_steps + 16, use_graph=use_graph)
+            mr, batch = decode_loop.build_decode_state(cfg, bs, ctx, ps, 2 * args.e2e_steps + 24, use_graph=use_graph)
         except Exception as e:  # graph capture refused (e.g. a collective that cannot be captured): run eagerly
             if not use_graph:
                 raise
             info["graph_error"] = f"{type(e).__name__}: {e}"[:200]
             use_graph = False
             torch.cuda.synchronize()
-            mr, batch = decode_loop.build_decode_state(cfg, bs, ctx, ps, args.e2e_steps + 16, use_graph=False)
+            mr, batch = decode_loop.build_decode_state(cfg, bs, ctx, ps, 2 * args.e2e_steps + 24, use_graph=False)
         dt = decode_loop.time_decode(mr, batch, args.e2e_steps, 4, barrier=barrier)
         if world > 1:
             import torch.distributed as dist
@@ -276,6 +276,17 @@ def decode_e2e(args, world, rank, barrier):
             dt = float(t[0])
         info.update({"tok_per_s": round(bs * args.e2e_steps / dt, 1), "ms_per_step": round(dt / args.e2e_steps * 1e3, 3),
                      "steps": args.e2e_steps, "hip_graph": use_graph})
+        if use_graph:
+            try:  # the same steps chained on the device, 8 per host synchronisation
+                dt = decode_loop.time_decode_chained(mr, batch, args.e2e_steps, 2, chain=8, barrier=barrier)
+                if world > 1:
+                    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    dt = float(t[0])
+                info.update({"tok_per_s_chained": round(bs * args.e2e_steps / dt, 1),
+                             "ms_per_step_chained": round(dt / args.e2e_steps * 1e3, 3), "chain": 8})
+            except Exception as e:
+                info["chained_error"] = f"{type(e).__name__}: {e}"[:200]
         return info
     except Exception as e:  # the headline number above must survive a failure here
         return {"error": f"{type(e).__name__}: {e}"[:300]}

@@ -87,3 +87,28 @@ def time_decode(mr: ModelRunner, batch: BatchInfo, steps: int, warmup: int, barr
         barrier()
     torch.cuda.synchronize()
     return time.perf_counter() - t0
+
+
+def time_decode_chained(mr: ModelRunner, batch: BatchInfo, steps: int, warmup: int, chain: int = 8, barrier=None) -> float:
+    """Seconds for `steps` decode steps run `chain` at a time on the device (DeviceDecodeLoop: preparation,
+    forward and greedy sampling captured together, one host synchronisation and token read-back per chain)."""
+    from .device_decode import DeviceDecodeLoop
+
+    loop = DeviceDecodeLoop(mr, batch, max_steps=max(chain, warmup))
+    if warmup:
+        loop.run(warmup)
+        loop.sync_host()
+    if barrier is not None:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = 0
+    while done < steps:
+        k = min(chain, steps - done)
+        loop.run(k)
+        loop.sync_host()
+        done += k
+    if barrier is not None:
+        barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0

@@ -10,8 +10,11 @@ cfg = {'8b':Qwen3Config.qwen3_8b,'0.6b':Qwen3Config.qwen3_0_6b,'32b':Qwen3Config
 if a.model=='0.6b': cfg.tie_word_embeddings=False
 if a.layers: cfg.num_hidden_layers=a.layers
 t0=time.time()
-mr,batch=dl.build_decode_state(cfg,a.bs,a.ctx,a.ps,a.steps+16,use_graph=not a.nograph)
+mr,batch=dl.build_decode_state(cfg,a.bs,a.ctx,a.ps,2*a.steps+32,use_graph=not a.nograph)
 torch.cuda.synchronize(); print('setup s',time.time()-t0, 'mem GB', torch.cuda.memory_allocated()/1e9, flush=True)
 dt=dl.time_decode(mr,batch,a.steps,5)
 print(json.dumps(dict(model=a.model,bs=a.bs,ctx=a.ctx,ps=a.ps,ms_per_step=dt/a.steps*1e3,tok_s=a.bs*a.steps/dt,graph=not a.nograph)))
+if not a.nograph:
+    dt=dl.time_decode_chained(mr,batch,a.steps,2,chain=10)
+    print(json.dumps(dict(model=a.model,bs=a.bs,ctx=a.ctx,ps=a.ps,ms_per_step_chained=dt/a.steps*1e3,tok_s_chained=a.bs*a.steps/dt)))
 print([r.token_ids[-4:] for r in batch.reqs[:2]])
