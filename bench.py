@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-e2e", action="store_true", help="skip the full-model decode tok/s measurement")
     ap.add_argument("--no-extend", action="store_true", help="skip the prefill-attention TFLOP/s measurement")
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary decode-attention configurations")
     ap.add_argument("--e2e-ctx", type=int, default=0, help="0 = 8192 if the whole-model KV fits in HBM, else the largest power of two that does")
     ap.add_argument("--e2e-steps", type=int, default=16)
     ap.add_argument("--e2e-eager", action="store_true", help="do not capture decode steps in hipGraphs")
@@ -182,6 +183,8 @@ def main():
         result["roofline"]["traffic_source"] = "profiles/r01_decode_bs256_ctx8192.md"
     del pools, qs, ws, out
     torch.cuda.empty_cache()
+    if not args.no_configs:
+        result["other_configs"] = other_decode_configs(args, world, rank)
     if not args.no_extend:
         result["extend"] = extend_attention(args, world, rank)
     if not args.no_e2e:
@@ -192,6 +195,68 @@ def main():
         import torch.distributed as dist
 
         dist.destroy_process_group()
+
+
+def other_decode_configs(args, world, rank):
+    """Decode attention (one layer per launch, same accounting as the headline: algorithmic KV bytes, no
+    de-duplication of shared prefixes) on the other single-layer shapes the benchmark family names: Qwen3-0.6B
+    batch 64 x 2k at page_size 1, and Qwen3-8B batch 256 with mixed 1k-32k contexts where groups of 16 requests
+    share a page-aligned 1-4k radix prefix.  Per-GPU figures under TP (heads divided like the headline)."""
+    from mini_sglang_amd import ops
+    from mini_sglang_amd.attn.hip_attn_backend import splits_for_batch
+    from mini_sglang_amd.runtime import workload
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    D = 128
+    out = {}
+
+    def run(name, Hq, Hkv, ps, lens, groups=None, prefix=None, layers=2, steps=12):
+        bs = len(lens)
+        pages = sum(-(-n // ps) for n in lens) + 8
+        pt = workload.make_page_table(lens, ps, pages, 3, groups=groups, group_prefix_lens=prefix)
+        slots = (pages + 1) * ps
+        pools = [torch.empty((slots, 2, Hkv, D), dtype=torch.bfloat16, device=dev).normal_() for _ in range(layers)]
+        q = torch.randn((bs, Hq, D), device=dev).bfloat16()
+        o = torch.empty_like(q)
+        r2t, sl = pt.req_to_token.to(dev), pt.seq_lens.to(dev)
+        idx = torch.arange(bs, dtype=torch.int32, device=dev)
+        ms = splits_for_batch(bs)
+        chunk = ops.pick_split(max(lens), sum(lens), bs, ms)
+        ms = max(1, min(ms, -(-max(lens) // chunk)))
+        ws = torch.empty(max(16, ops.decode_workspace_bytes(bs, Hq, D, ms)), dtype=torch.uint8, device=dev)
+        reuse = torch.tensor([prefix[g] for g in groups], dtype=torch.int32, device=dev) if groups is not None else None
+
+        def f(i):
+            kv = pools[i % layers]
+            ops.paged_decode(q, kv[:, 0], kv[:, 1], r2t, idx, sl, D ** -0.5, ps, out=o, workspace=ws, max_splits=ms,
+                             chunk_tokens=chunk, reuse_lens=reuse)
+
+        for i in range(4):
+            f(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(steps):
+            f(i)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / steps * 1e-3
+        b = 2 * Hkv * D * 2
+        out[name] = {"GBps_per_gpu": round(b * sum(lens) / t / 1e9, 1), "unique_GBps_per_gpu": round(b * pt.unique_tokens / t / 1e9, 1),
+                     "ms_per_launch": round(t * 1e3, 4), "frac_of_hbm_peak": round(b * sum(lens) / t / 1e9 / HBM_PEAK_GBPS, 4)}
+
+    try:
+        if world == 1:
+            run("qwen3_0.6b_bs64_ctx2048_ps1", 16, 8, 1, [2048] * 64, layers=8)
+        lens = workload.mixed_lengths(256, 1024, 32768, 3)
+        groups = [i // 16 for i in range(256)]
+        prefix = [1024 * (1 + g % 4) for g in range(16)]
+        lens = [max(n, prefix[g] + 16) for n, g in zip(lens, groups)]
+        run("qwen3_8b_bs256_mixed_1k_32k_ps16_radix_shared", args.hq // world, args.hkv // world, 16, lens, groups, prefix)
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
+    torch.cuda.empty_cache()
+    return out
 
 
 def extend_attention(args, world, rank):
