@@ -318,15 +318,11 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
     int t = 0;
     // ---- steady state: tile t+1 is visible to every row of the wave ----
     for (; t + 1 < full_nkt; ++t) {
-#ifndef MSGL_EXP_NOBARRIER
         __syncthreads();
-#endif
         rescale_o(alpha_pend);  // a branch of its own, ahead of the block below, so that nothing of that block sinks behind it
-#ifndef MSGL_EXP_NOSTAGE
         stage_write<KPT, KSTEP>(lds + nn, skey, c16, stg);
         stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);  // tile t+3
         slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + 4, nkt - 1), skey, kv_len);
-#endif
 
         // S^T of tile t+1 (reads two k-steps ahead of the matrix instructions), the row sum of tile t beside it
         f32x16_t s0, s1;
