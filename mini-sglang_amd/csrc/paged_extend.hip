@@ -68,6 +68,13 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// max of m and eight more values: four chained v_max3_f32 in one statement (no padding between them)
+__device__ __forceinline__ float max9_raw(float m, float a, float b, float c, float d, float e, float f, float g, float h) {
+    asm("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %0, %0, %7, %8"
+        : "+v"(m)
+        : "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g), "v"(h));
+    return m;
+}
 
 // max over the two lanes that share a query column (lane, lane ^ 32): one v_permlane32_swap
 __device__ __forceinline__ float max_with_lane_xor32(float x) {
@@ -362,8 +369,9 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf[d]), as_bf16x8(pf[0]), o[d], 0, 0, 0);
-#pragma unroll
-            for (int r = 3 + 8 * d; r < 11 + 8 * d && r < 31; r += 2) mx = max3_raw(mx, st[r], st[r + 1]);
+            const int r = 3 + 8 * d;  // d = 3 runs past the end: st[30] repeated, the last value (st[31]) is taken below
+            mx = max9_raw(mx, st[r], st[r + 1], st[r + 2], st[r + 3], st[min(r + 4, 30)], st[min(r + 5, 30)], st[min(r + 6, 30)],
+                          st[min(r + 7, 30)]);
             __builtin_amdgcn_sched_barrier(0);
         }
         const float mn = fmaxf(m, max_with_lane_xor32(fmaxf(mx, st[31])) * p.scale_log2e);
