@@ -97,7 +97,7 @@ def main():
     qs = [synth.normal((bs, Hq, D), 900 + layer + rank, device=dev) for layer in range(L)]
     out = torch.empty((bs, Hq, D), dtype=torch.bfloat16, device=dev)
     max_splits = args.max_splits or splits_for_batch(bs)
-    chunk = args.chunk or ops.pick_split(S, S * bs, bs, max_splits)
+    chunk = args.chunk or ops.pick_split(S, S * bs, bs, max_splits, Hkv)
     if not args.graph_grid:
         # an eager call knows the longest context on the host and launches only the splits it needs, exactly as
         # HipAttnBackend.init_forward_metadata does; --graph-grid keeps the length-independent grid of a captured step
@@ -221,7 +221,7 @@ def other_decode_configs(args, world, rank):
         r2t, sl = pt.req_to_token.to(dev), pt.seq_lens.to(dev)
         idx = torch.arange(bs, dtype=torch.int32, device=dev)
         ms = splits_for_batch(bs)
-        chunk = ops.pick_split(max(lens), sum(lens), bs, ms)
+        chunk = ops.pick_split(max(lens), sum(lens), bs, ms, Hkv)
         ms = max(1, min(ms, -(-max(lens) // chunk)))
         ws = torch.empty(max(16, ops.decode_workspace_bytes(bs, Hq, D, ms)), dtype=torch.uint8, device=dev)
         reuse = torch.tensor([prefix[g] for g in groups], dtype=torch.int32, device=dev) if groups is not None else None

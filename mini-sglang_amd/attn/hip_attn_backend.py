@@ -70,9 +70,9 @@ class HipAttnBackend(AttentionBackend):
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._workspace
 
-    @staticmethod
-    def _decode_split(seq_lens_cpu: torch.Tensor, bs: int, max_splits: int) -> int:
-        return ops.pick_split(int(seq_lens_cpu.max()), int(seq_lens_cpu.sum()), bs, max_splits)
+    def _decode_split(self, seq_lens_cpu: torch.Tensor, bs: int, max_splits: int) -> int:
+        kv_heads = int(getattr(self.kv_cache_pool, "head_num", 8))
+        return ops.pick_split(int(seq_lens_cpu.max()), int(seq_lens_cpu.sum()), bs, max_splits, kv_heads)
 
     # ------------------------------------------------------------------ eager metadata
     def init_forward_metadata(self, batch):

@@ -394,14 +394,18 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
     }
 }
 
-// Merge the split-K partials of one (request, query head).  256 threads: the 4 waves take every 4th
-// split, lane l owns output columns 2l and 2l+1; split weights are formed once (all threads, in
-// parallel over splits) and kept in LDS, so the per-split work is two independent loads and two FMAs.
+// Merge the split-K partials of one (request, query head).  NW waves take every NW-th split, lane l owns
+// output columns 2l and 2l+1; each thread reads the (max, sum) pairs of its splits once, the split weights
+// are formed in parallel and kept in LDS, so the per-split work is one 8-byte load and two FMAs, four
+// splits in flight per wave.
 constexpr int kMergeMaxSplits = 4096;
-__global__ __launch_bounds__(256) void paged_decode_merge_kernel(DecodeParams p) {
-    __shared__ float red[4];
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void paged_decode_merge_kernel(DecodeParams p) {
+    constexpr int NT = NW * 64;
+    constexpr int PER = (kMergeMaxSplits + NT - 1) / NT;  // (max, sum) pairs a thread may own
+    __shared__ float red[NW];
     __shared__ float wts[kMergeMaxSplits];
-    __shared__ float part[4][kD];
+    __shared__ float part[NW][kD];
     const int b = blockIdx.x / p.Hq;
     const int hq = blockIdx.x - b * p.Hq;
     const int S = p.seq_lens[b];
@@ -411,31 +415,58 @@ __global__ __launch_bounds__(256) void paged_decode_merge_kernel(DecodeParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row0 = ((int64_t)b * p.max_splits) * p.Hq + hq;
     // running max over splits
+    float2 ml[PER];
     float M = kNegBig;
-    for (int s = tid; s < nsplit; s += 256) M = fmaxf(M, p.ws_ml[(row0 + (int64_t)s * p.Hq) * 2]);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int s = tid + i * NT;
+        ml[i] = s < nsplit ? *reinterpret_cast<const float2*>(p.ws_ml + (row0 + (int64_t)s * p.Hq) * 2) : make_float2(kNegBig, 0.f);
+        M = fmaxf(M, ml[i].x);
+    }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off));
     if (lane == 0) red[wave] = M;
     __syncthreads();
-    M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    M = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, red[w]);
     __syncthreads();
     // split weights and the normaliser
     float L = 0.f;
-    for (int s = tid; s < nsplit; s += 256) {
-        const float2 ml = *reinterpret_cast<const float2*>(p.ws_ml + (row0 + (int64_t)s * p.Hq) * 2);
-        const float f = fast_exp2(ml.x - M);
-        wts[s] = f;
-        L += f * ml.y;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int s = tid + i * NT;
+        if (s < nsplit) {
+            const float f = fast_exp2(ml[i].x - M);
+            wts[s] = f;
+            L += f * ml[i].y;
+        }
     }
     L = wave_sum(L);
     if (lane == 0) red[wave] = L;
     __syncthreads();
-    L = red[0] + red[1] + red[2] + red[3];
+    L = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) L += red[w];
     // weighted sum of the partial outputs
     const int d = lane * 2;
+    const float* src = p.ws_o + row0 * kD + d;
+    const int64_t step = (int64_t)p.Hq * kD;
     float o0 = 0.f, o1 = 0.f;
-    for (int s = wave; s < nsplit; s += 4) {
-        const float2 o = *reinterpret_cast<const float2*>(p.ws_o + (row0 + (int64_t)s * p.Hq) * kD + d);
+    int s = wave;
+    for (; s + 3 * NW < nsplit; s += 4 * NW) {
+        const float2 a0 = *reinterpret_cast<const float2*>(src + (int64_t)s * step);
+        const float2 a1 = *reinterpret_cast<const float2*>(src + (int64_t)(s + NW) * step);
+        const float2 a2 = *reinterpret_cast<const float2*>(src + (int64_t)(s + 2 * NW) * step);
+        const float2 a3 = *reinterpret_cast<const float2*>(src + (int64_t)(s + 3 * NW) * step);
+        const float f0 = wts[s], f1 = wts[s + NW], f2 = wts[s + 2 * NW], f3 = wts[s + 3 * NW];
+        o0 = fmaf(f0, a0.x, o0), o1 = fmaf(f0, a0.y, o1);
+        o0 = fmaf(f1, a1.x, o0), o1 = fmaf(f1, a1.y, o1);
+        o0 = fmaf(f2, a2.x, o0), o1 = fmaf(f2, a2.y, o1);
+        o0 = fmaf(f3, a3.x, o0), o1 = fmaf(f3, a3.y, o1);
+    }
+    for (; s < nsplit; s += NW) {
+        const float2 o = *reinterpret_cast<const float2*>(src + (int64_t)s * step);
         const float f = wts[s];
         o0 = fmaf(f, o.x, o0);
         o1 = fmaf(f, o.y, o1);
@@ -444,8 +475,9 @@ __global__ __launch_bounds__(256) void paged_decode_merge_kernel(DecodeParams p)
     part[wave][d + 1] = o1;
     __syncthreads();
     if (wave == 0) {
-        o0 = part[0][d] + part[1][d] + part[2][d] + part[3][d];
-        o1 = part[0][d + 1] + part[1][d + 1] + part[2][d + 1] + part[3][d + 1];
+        o0 = part[0][d], o1 = part[0][d + 1];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) o0 += part[w][d], o1 += part[w][d + 1];
         const float inv = 1.0f / L;
         *reinterpret_cast<uint32_t*>(p.out + (int64_t)b * p.out_stride + hq * kD + d) = pack_bf16(o0 * inv, o1 * inv);
     }
@@ -462,7 +494,10 @@ static int launch_decode(const DecodeParams& p, int page_size, hipStream_t strea
     int rc = check_launch("paged_decode_kernel");
     if (rc) return rc;
     if (p.max_splits > 1) {
-        hipLaunchKernelGGL(paged_decode_merge_kernel, dim3(p.bs * p.Hq), dim3(256), 0, stream, p);
+        if (p.max_splits <= 16)  // few splits: 4 waves already cover them
+            hipLaunchKernelGGL(paged_decode_merge_kernel<4>, dim3(p.bs * p.Hq), dim3(256), 0, stream, p);
+        else
+            hipLaunchKernelGGL(paged_decode_merge_kernel<16>, dim3(p.bs * p.Hq), dim3(1024), 0, stream, p);
         rc = check_launch("paged_decode_merge_kernel");
     }
     return rc;

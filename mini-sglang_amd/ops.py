@@ -143,16 +143,22 @@ def paged_decode(
     return out
 
 
-def pick_split(seq_lens_cpu_max: int, total_tokens: int, bs: int, max_splits: int) -> int:
+def pick_split(seq_lens_cpu_max: int, total_tokens: int, bs: int, max_splits: int, local_kv_heads: int = 8) -> int:
     """Tokens per split for the decode kernel: a multiple of DECODE_TILE such that the longest sequence fits
-    max_splits splits.  Uniform batches get about two work groups per CU (long splits amortise a group's
-    prologue and merge); ragged batches get about eight, so that short requests and the tails of long ones
-    even out over the 256 CUs."""
+    max_splits splits.  Measured on MI355X (256 CUs): small batches run best with about one work group per CU,
+    large uniform ones with two (long splits amortise a group's prologue and merge), ragged ones with about
+    eight, so that short requests and the tails of long ones even out.  A split is never shorter than four
+    16-token tiles per wave; with fewer than 8 local kv heads several waves share a head and a split."""
+    waves_per_head = max(1, 8 // max(1, min(8, local_kv_heads)))
+    min_chunk = max(128, 64 * waves_per_head)
     ragged = seq_lens_cpu_max * bs > 1.25 * total_tokens
-    target_groups = 2048 if ragged else 512
+    if ragged:
+        target_groups = 2048
+    else:
+        target_groups = 256 if total_tokens <= 256 * 1024 else 512
     per_group = max(1, -(-total_tokens // target_groups))
     floor_ = -(-max(seq_lens_cpu_max, 1) // max_splits)
-    chunk = max(per_group, floor_, 512)
+    chunk = max(per_group, floor_, min_chunk)
     return -(-chunk // DECODE_TILE) * DECODE_TILE
 
 

@@ -24,7 +24,7 @@ def run(name, Hq, Hkv, ps, seq_lens, groups=None, prefix=None, layers=4, steps=2
     q = torch.randn((bs, Hq, D), device=dev).bfloat16()
     r2t, sl, idx = pt.req_to_token.to(dev), pt.seq_lens.to(dev), torch.arange(bs, dtype=torch.int32, device=dev)
     ms_ = max_splits or splits_for_batch(bs)
-    ch = chunk or ops.pick_split(max(seq_lens), sum(seq_lens), bs, ms_)
+    ch = chunk or ops.pick_split(max(seq_lens), sum(seq_lens), bs, ms_, Hkv)
     ws = torch.empty(max(16, ops.decode_workspace_bytes(bs, Hq, D, ms_)), dtype=torch.uint8, device=dev)
     out = torch.empty_like(q)
     reuse = torch.tensor([prefix[g] for g in groups], dtype=torch.int32, device=dev) if groups is not None else None
@@ -67,4 +67,6 @@ if "tp8" in which:
 if "cfg5" in which:
     run("cfg5 32B TP8 shard bs1 128k ps64", 8, 1, 64, [131072], layers=8)
     run("cfg5 32B TP8 shard bs8 128k ps64", 8, 1, 64, [131072] * 8, layers=8)
+    run("8B bs1 32k ps16", 32, 8, 16, [32768], layers=8)
+    run("8B bs8 8k ps16", 32, 8, 16, [8192] * 8, layers=8)
     run("32B TP1 bs64 8k ps16", 64, 8, 16, [8192] * 64)
