@@ -18,6 +18,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import torch
@@ -49,6 +50,8 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the full-model decode tok/s measurement")
     ap.add_argument("--no-extend", action="store_true", help="skip the prefill-attention TFLOP/s measurement")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary decode-attention configurations")
+    ap.add_argument("--secondary-deadline", type=float, default=420.0,
+                    help="seconds the measurements after the headline may take before the line is printed without them")
     ap.add_argument("--e2e-ctx", type=int, default=0, help="0 = 8192 if the whole-model KV fits in HBM, else the largest power of two that does")
     ap.add_argument("--e2e-steps", type=int, default=16)
     ap.add_argument("--e2e-eager", action="store_true", help="do not capture decode steps in hipGraphs")
@@ -183,14 +186,32 @@ def main():
         result["roofline"]["traffic_source"] = "profiles/r01_decode_bs256_ctx8192.md"
     del pools, qs, ws, out
     torch.cuda.empty_cache()
+    # The secondary measurements below must never cost the headline line: if one of them is still running
+    # after the deadline (a collective that never completes under TP, say), every rank gives up together and
+    # rank 0 prints what it has.
+    printed = threading.Event()
+
+    def emit():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            print(json.dumps(result), flush=True)
+
+    def give_up():
+        result["secondary_timeout_s"] = args.secondary_deadline
+        emit()
+        os._exit(0)
+
+    watchdog = threading.Timer(args.secondary_deadline, give_up)
+    watchdog.daemon = True
+    watchdog.start()
     if not args.no_configs:
         result["other_configs"] = other_decode_configs(args, world, rank)
     if not args.no_extend:
         result["extend"] = extend_attention(args, world, rank)
     if not args.no_e2e:
         result["decode_e2e"] = decode_e2e(args, world, rank, barrier)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    watchdog.cancel()
+    emit()
     if world > 1:
         import torch.distributed as dist
 

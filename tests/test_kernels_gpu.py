@@ -132,6 +132,34 @@ def test_decode_shared_prefix_rows():
         assert torch.equal(run_decode(case, ps, max_splits=8, chunk_tokens=128, **kw), base)
 
 
+def test_decode_full_size_properties():
+    """The headline shape (batch 256 x 8192 tokens, page_size 16, 32 q / 8 kv heads; 8.6 GB of K/V) through
+    properties that do not need the CPU oracle for the whole batch: the split size does not change the result
+    beyond rounding, permuting the requests permutes the outputs bit for bit, and sampled requests agree with
+    an fp64 evaluation."""
+    ops = _ops()
+    synth, workload = _synth()
+    bs, S, ps, Hq, Hkv, D = 256, 8192, 16, 32, 8, 128
+    pages = bs * (S // ps) + 8
+    pt = workload.make_page_table([S] * bs, ps, pages, seed=9)
+    torch.manual_seed(91)
+    kv = torch.empty(((pages + 1) * ps, 2, Hkv, D), dtype=torch.bfloat16, device=DEV).normal_()
+    q = synth.normal((bs, Hq, D), 92, device=DEV)
+    r2t, lens = pt.req_to_token.to(DEV), pt.seq_lens.to(DEV)
+    idx = torch.arange(bs, dtype=torch.int32, device=DEV)
+    run = lambda qq, ii, **kw: ops.paged_decode(qq, kv[:, 0], kv[:, 1], r2t, ii, lens, D ** -0.5, ps, **kw)
+    a = run(q, idx, max_splits=2, chunk_tokens=4096)
+    b = run(q, idx, max_splits=16, chunk_tokens=512)
+    assert (a.float() - b.float()).abs().max().item() <= 2e-2
+    perm = synth.permutation(bs, 93).to(DEV)
+    c = run(q[perm].contiguous(), idx[perm].contiguous(), max_splits=2, chunk_tokens=4096)
+    assert torch.equal(c, a[perm])
+    for r in (0, 100, 255):
+        rows = kv[r2t[r, :S].long()].cpu()  # the request's K/V rows in token order
+        exact = orc.paged_attention_fp64(q[r: r + 1].cpu(), rows[:, 0], rows[:, 1], torch.arange(S), D ** -0.5)[0]
+        assert_close_fp64(a[r].cpu(), exact, f"request {r} of the headline batch")
+
+
 def test_decode_long_context_split():
     case = build_case(8, 1, 64, [20000, 3], seed=9)
     check_decode(case, run_decode(case, 64, max_splits=128, chunk_tokens=256))
@@ -193,9 +221,12 @@ def check_extend(case, out):
         start += n
 
 
+@pytest.mark.parametrize("heads_per_group", [1, 2])
 @pytest.mark.parametrize("Hq,Hkv", [(16, 8), (32, 8), (8, 1), (4, 4)])
 @pytest.mark.parametrize("page_size", [1, 16, 64])
-def test_extend(Hq, Hkv, page_size):
+def test_extend(Hq, Hkv, page_size, heads_per_group, monkeypatch):
+    # both work-group shapes of the kernel (one or two query heads per group); the library reads the override per call
+    monkeypatch.setenv("MSGL_EXTEND_NH", str(heads_per_group))
     ps = page_size
     prefix = [0, 0, ps * 2, 0, 64 * ps // ps * (ps if ps > 1 else 1), 0]
     prefix = [p - p % ps for p in prefix]
@@ -204,9 +235,32 @@ def test_extend(Hq, Hkv, page_size):
     check_extend(case, run_extend(case, ps))
 
 
-def test_extend_long_prefix():
+@pytest.mark.parametrize("heads_per_group", [1, 2])
+def test_extend_long_prefix(heads_per_group, monkeypatch):
+    monkeypatch.setenv("MSGL_EXTEND_NH", str(heads_per_group))
     case = build_extend_case(16, 8, 16, [2048, 0], [130, 700], seed=21)
     check_extend(case, run_extend(case, 16))
+
+
+def test_extend_full_size_rows_match_decode_and_fp64():
+    """A 4096-token prompt on top of a 1024-token cached prefix, Qwen3-8B heads (too large for the CPU oracle as
+    a whole): sampled query rows must equal what the decode kernel returns for the same query over the same
+    visible keys (row i of the extend == a decode step at length prefix + i + 1), and an fp64 evaluation."""
+    ops = _ops()
+    ps, P, n, Hq, Hkv = 16, 1024, 4096, 32, 8
+    case = build_extend_case(Hq, Hkv, ps, [P], [n], seed=31)
+    out = run_extend(case, ps)
+    rows = [0, 1, 31, 32, 63, 64, 127, 128, 1000, 2047, 2048, 4000, 4095]
+    kvd = case["kv"].to(DEV)
+    q = case["q"][rows].contiguous().to(DEV)
+    lens = torch.tensor([P + r + 1 for r in rows], dtype=torch.int32, device=DEV)
+    idx = torch.zeros(len(rows), dtype=torch.int32, device=DEV)
+    dec = ops.paged_decode(q, kvd[:, 0], kvd[:, 1], case["r2t"].to(DEV), idx, lens, 128 ** -0.5, ps, max_splits=8,
+                           chunk_tokens=1024).cpu()
+    assert (out[rows].float() - dec.float()).abs().max().item() <= 2e-2
+    exact = orc.paged_attention_fp64(case["q"][rows], case["kv"][:, 0], case["kv"][:, 1], case["r2t"][0, : P + n], 128 ** -0.5,
+                                     q_positions=torch.tensor([P + r for r in rows]))
+    assert_close_fp64(out[rows], exact, "sampled rows of the 4096-token extend")
 
 
 # ------------------------------------------------------------------------------------------------ layers
