@@ -1,4 +1,6 @@
 from .req2token import ReqToTokenPool
 from .token2kv import MHAKVPool, PageAllocator
 
-__all__ = ["ReqToTokenPool", "MHAKVPool", "PageAllocator"]
+from .radix_cache import MatchResult, RadixCache
+
+__all__ = ["ReqToTokenPool", "MHAKVPool", "PageAllocator", "RadixCache", "MatchResult"]

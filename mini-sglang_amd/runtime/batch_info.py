@@ -53,6 +53,7 @@ class Req:
         # slots of an already-cached prefix (set by a prefix cache before prepare_for_extend); int32, CPU or device
         self.prefix_indices: torch.Tensor = torch.empty(0, dtype=torch.int32)
         self.last_slot: int = -1  # pool slot of the request's last stored token
+        self.last_node = None     # radix-cache node that ends the cached prefix (a handle; None = no cache)
 
     @property
     def last_token_id(self) -> int:

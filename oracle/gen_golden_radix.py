@@ -87,6 +87,16 @@ def tree_ops(seed: int, page_size: int, n_ops: int = 500):
     return ops
 
 
+def attached(tree, node) -> bool:
+    """True while `node` is still part of the tree (eviction detaches nodes; a scheduler never locks those)."""
+    while node is not tree.root:
+        parent = node.parent
+        if parent is None or not any(c is node for c in parent.children.values()):
+            return False
+        node = parent
+    return True
+
+
 def run_tree_ops(RadixCache, ops, page_size):
     freed = []
 
@@ -107,7 +117,8 @@ def run_tree_ops(RadixCache, ops, page_size):
             recent.insert(0, res.last_node)
             del recent[8:]
         elif op[0] == "lock":
-            if op[1] < len(recent):
+            rec["done"] = op[1] < len(recent) and attached(tree, recent[op[1]])
+            if rec["done"]:
                 tree.inc_lock_ref(recent[op[1]])
                 locked.append(recent[op[1]])
         elif op[0] == "unlock":
