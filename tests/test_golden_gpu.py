@@ -155,3 +155,65 @@ def test_device_chained_decode_equals_host_prepared_steps(ps):
     for ra, rb in zip(batch_a.reqs, batch_b.reqs):
         n = len(ra.token_ids)
         assert torch.equal(mr_a.req_to_token_pool.req_to_token[ra.req_pool_idx, :n], mr_b.req_to_token_pool.req_to_token[rb.req_pool_idx, :n])
+
+
+@pytest.mark.parametrize("ps", [1, 16])
+def test_radix_cache_hit_generates_the_same_tokens(ps):
+    """A second request that shares a prompt prefix with a finished one is prefilled on top of the cached slots
+    (RadixCache.match_prefix -> prefix_indices -> extend with prefix > 0) and must generate exactly the tokens a
+    cold run of the same request generates; its page-table row starts with the first request's slots."""
+    from mini_sglang_amd.mem_cache import MHAKVPool, PageAllocator, RadixCache, ReqToTokenPool
+    from mini_sglang_amd.runtime import synth
+    from mini_sglang_amd.runtime.batch_info import BatchInfo, Req, SamplingParams
+    from mini_sglang_amd.runtime.model_runner import ModelConfig, ModelRunner, ServerArgs
+    from mini_sglang_amd.runtime.qwen3 import Qwen3Config
+
+    cfg = Qwen3Config(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                      intermediate_size=512, vocab_size=2048, max_position_embeddings=1024, tie_word_embeddings=False)
+    shared = synth.uniform_int(70, 5, 0, 2048).tolist()
+    prompt_a = shared + synth.uniform_int(9, 6, 0, 2048).tolist()
+    prompt_b = shared + synth.uniform_int(21, 7, 0, 2048).tolist()
+    new = 12
+
+    def generate(prompts, use_cache):
+        args = ServerArgs(page_size=ps, device=DEV, disable_cuda_graph=True, max_num_reqs=4, random_seed=8, weight_std=0.02,
+                          embed_std=0.3, successor_head=0.04)
+        pages = 1024 // ps
+        r2t = ReqToTokenPool(4, cfg.max_position_embeddings, ps, DEV)
+        pa = PageAllocator(pages, ps)
+        kv = MHAKVPool(pages * ps, ps, torch.bfloat16, cfg.num_key_value_heads, cfg.head_dim, cfg.num_hidden_layers, DEV)
+        mr = ModelRunner(ModelConfig(cfg), args, req_to_token_pool=r2t, page_allocator=pa, kv_cache_pool=kv)
+        tree = RadixCache(r2t, kv, pa, ps) if use_cache else None
+        out, rows, hits = [], [], []
+        for i, p in enumerate(prompts):
+            req = Req(i, p, SamplingParams(0.0))
+            if tree is not None:
+                m = tree.match_prefix(req.token_ids[:-1])
+                req.prefix_indices, req.last_node = m.match_indices, m.last_node
+                tree.inc_lock_ref(req.last_node)
+            hits.append(int(req.prefix_indices.numel()))
+            batch = BatchInfo.init_new([req], r2t, pa, kv, tree_cache=tree)
+            batch.prepare_for_extend()
+            lg, _ = mr.forward_generate(batch)
+            mr.process_result(batch, lg)
+            if tree is not None:
+                tree.cache_unfinished_req(req)
+            for _ in range(new - 1):
+                batch.prepare_for_decode()
+                lg, _ = mr.forward_generate(batch)
+                mr.process_result(batch, lg)
+            out.append(req.token_ids[len(p):])
+            rows.append(r2t.req_to_token[req.req_pool_idx, : len(p)].cpu().clone())
+            if tree is not None:
+                tree.cache_finished_req(req)
+            else:
+                r2t.free(req.req_pool_idx)
+        return out, rows, hits, tree
+
+    cold_a, _, _, _ = generate([prompt_a], False)
+    cold_b, _, _, _ = generate([prompt_b], False)
+    warm, rows, hits, tree = generate([prompt_a, prompt_b], True)
+    assert hits[0] == 0 and hits[1] == 70 // ps * ps, hits
+    assert warm[0] == cold_a[0] and warm[1] == cold_b[0]
+    assert torch.equal(rows[1][: hits[1]], rows[0][: hits[1]]), "the second request reads the first one's slots"
+    assert tree.protected_size() == 0 and tree.evictable_size() > 0
