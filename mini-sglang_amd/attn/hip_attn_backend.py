@@ -38,9 +38,9 @@ class HipAttnMetadata:
 
 def splits_for_batch(bs: int) -> int:
     """Upper bound on splits per request (the launch has bs * splits work groups, most of which exit at once
-    for short requests): up to 8192 groups in all, so a 32k-token request in a batch of 256 can still be cut
-    into 1k-token pieces, and a single 128k-token request into 512."""
-    return max(1, min(512, -(-8192 // max(bs, 1))))
+    for short requests, at about 2 ns each): up to 4096 groups in all, so a 32k-token request in a batch of 256
+    can still be cut into 2k-token pieces, and a single 128k-token request into 512."""
+    return max(1, min(512, -(-4096 // max(bs, 1))))
 
 
 class HipAttnBackend(AttentionBackend):
