@@ -235,6 +235,74 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(uint16_t* qkv, i
     }
 }
 
+// The same work for large T: a 16-lane row owns HPR consecutive heads of one token, so the position's
+// cos / sin entries and the norm weights are read once per row instead of once per head, and the HPR
+// 16-byte loads of the row are all in flight before the first head is processed.
+template <bool ROUND_REF, int HPR>
+__global__ __launch_bounds__(256) void qknorm_rope_store_rows_kernel(uint16_t* qkv, int64_t qkv_stride, const uint16_t* qw,
+                                                                     const uint16_t* kw, float eps, const int32_t* positions,
+                                                                     const float* cache, const int32_t* loc, uint16_t* kc,
+                                                                     uint16_t* vc, int64_t cache_stride, int T, int Hq,
+                                                                     int Hkv) {
+    constexpr int D = 128;
+    const int H = Hq + 2 * Hkv;
+    const int groups = (H + HPR - 1) / HPR;  // rows per token
+    const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int c = threadIdx.x & 15;
+    if (item >= (int64_t)T * groups) return;  // whole 16-lane rows leave together
+    const int t = (int)(item / groups);
+    const int h0 = (int)(item - (int64_t)t * groups) * HPR;
+    uint16_t* src = qkv + (int64_t)t * qkv_stride + h0 * D + c * 8;
+    uint4 raw[HPR];
+#pragma unroll
+    for (int i = 0; i < HPR; ++i) raw[i] = (h0 + i < H) ? *reinterpret_cast<const uint4*>(src + i * D) : make_uint4(0, 0, 0, 0);
+    float wq[8], wk[8], cs[8], sn[8];
+    unpack8(*reinterpret_cast<const uint4*>(qw + c * 8), wq);
+    unpack8(*reinterpret_cast<const uint4*>(kw + c * 8), wk);
+    {
+        const float* cp = cache + (int64_t)positions[t] * D + (c & 7) * 8;
+        const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+        const float4 s0 = *reinterpret_cast<const float4*>(cp + 64), s1 = *reinterpret_cast<const float4*>(cp + 68);
+        const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] = cc[e], sn[e] = ss[e];
+    }
+    const int64_t slot = loc != nullptr ? (int64_t)loc[t] * cache_stride : 0;
+#pragma unroll
+    for (int i = 0; i < HPR; ++i) {
+        const int hh = h0 + i;
+        if (hh >= H) break;
+        const bool is_v = hh >= Hq + Hkv;
+        const bool is_k = !is_v && hh >= Hq;
+        uint4 r4 = raw[i];
+        if (!is_v) {
+            float v[8];
+            unpack8(r4, v);
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss = fmaf(v[e], v[e], ss);
+            ss = row16_sum(ss);
+            const float r = rsqrt_nr(ss / 128.0f + eps);
+            float xn[8], xp[8], y1[8], y2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xn[e] = round_bf16((v[e] * r) * (is_k ? wk[e] : wq[e]));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xp[e] = dpp_f32<0x128>(xn[e]);
+            if (c < 8)
+                rope8<ROUND_REF>(xn, xp, cs, sn, y1, y2);
+            else
+                rope8<ROUND_REF>(xp, xn, cs, sn, y1, y2);
+            r4 = (c < 8) ? pack8(y1) : pack8(y2);
+            *reinterpret_cast<uint4*>(src + i * D) = r4;
+        }
+        if (loc != nullptr && (is_k || is_v)) {
+            const int hk = is_k ? hh - Hq : hh - Hq - Hkv;
+            *reinterpret_cast<uint4*>((is_k ? kc : vc) + slot + hk * D + c * 8) = r4;
+        }
+    }
+}
+
 // ---- greedy argmax over a vocab row: one 256-thread block per row ----
 template <typename T>
 __device__ __forceinline__ float to_f32(T v);
@@ -442,6 +510,18 @@ extern "C" int msgl_qknorm_rope_store(void* qkv, int64_t qkv_stride, const void*
     auto kw = static_cast<const uint16_t*>(k_norm_w);
     auto kc = static_cast<uint16_t*>(k_cache);
     auto vc = static_cast<uint16_t*>(v_cache);
+    constexpr int kHeadsPerRow = 8;
+    const int64_t row_items = (int64_t)T * ((Hq + 2 * Hkv + kHeadsPerRow - 1) / kHeadsPerRow);
+    if (row_items >= 16 * 2048) {  // enough rows to fill the chip several times over: amortise the per-token loads
+        const dim3 rgrid((unsigned)((row_items + 15) / 16));
+        if (rounding == 0)
+            hipLaunchKernelGGL((qknorm_rope_store_rows_kernel<true, kHeadsPerRow>), rgrid, block, 0, st, qp, qkv_stride, qw, kw, eps,
+                               positions, cos_sin_cache, loc, kc, vc, cache_stride, T, Hq, Hkv);
+        else
+            hipLaunchKernelGGL((qknorm_rope_store_rows_kernel<false, kHeadsPerRow>), rgrid, block, 0, st, qp, qkv_stride, qw, kw, eps,
+                               positions, cos_sin_cache, loc, kc, vc, cache_stride, T, Hq, Hkv);
+        return check_launch("qknorm_rope_store_rows");
+    }
     if (rounding == 0)
         hipLaunchKernelGGL((qknorm_rope_store_kernel<true>), grid, block, 0, st, qp, qkv_stride, qw, kw, eps, positions,
                            cos_sin_cache, loc, kc, vc, cache_stride, T, Hq, Hkv);

@@ -354,11 +354,12 @@ def test_store_kv_bit_exact():
         assert torch.equal(kcd.cpu(), kc) and torch.equal(vcd.cpu(), vc)
 
 
+@pytest.mark.parametrize("T", [33, 20000])  # 20000 tokens take the rows-of-8-heads kernel
 @pytest.mark.parametrize("Hq,Hkv", [(16, 8), (32, 8), (8, 1)])
-def test_fused_qknorm_rope_store(Hq, Hkv):
+def test_fused_qknorm_rope_store(Hq, Hkv, T):
     ops = _ops()
     synth, _ = _synth()
-    D, T, slots = 128, 33, 200
+    D, slots = 128, T + 167
     cache = orc.build_cos_sin_cache(D, 4096, 1e6)
     pos = synth.uniform_int(T, 13, 0, 4096).to(torch.int32)
     qkv = synth.normal((T, (Hq + 2 * Hkv) * D), 14, std=1.5)
@@ -378,8 +379,21 @@ def test_fused_qknorm_rope_store(Hq, Hkv):
     got = qkv_d.cpu()
     dq = ulp_diff_bf16(got[:, : Hq * D], q_ref)
     dk = ulp_diff_bf16(got[:, Hq * D: (Hq + Hkv) * D], k_ref)
-    # the norm may differ by one bf16 ulp on few elements (sum order / rsqrt); rope then mixes pairs, so allow 2
-    assert dq.max() <= 2 and dk.max() <= 2 and (dq > 0).float().mean() < 0.03, (dq.max(), dk.max(), (dq > 0).float().mean())
+    # the norm may differ by one bf16 ulp on few elements (sum order / rsqrt); rope then mixes pairs, so allow 2 —
+    # in ulps, or, where the rotation cancels to a small number, the same distance at the scale of its operands
+    far_q = (dq > 2) & ((got[:, : Hq * D].float() - q_ref.float()).abs() > 0.04)
+    far_k = (dk > 2) & ((got[:, Hq * D: (Hq + Hkv) * D].float() - k_ref.float()).abs() > 0.04)
+    assert not far_q.any() and not far_k.any() and (dq > 0).float().mean() < 0.03, (dq.max(), dk.max(), (dq > 0).float().mean())
+    if T > 1000:
+        # the rows-of-8-heads kernel and the head-per-row kernel (taken for few tokens) do the same arithmetic: bit equal
+        kv2 = torch.zeros_like(kvd)
+        parts = []
+        for a in range(0, T, 256):
+            part = qkv[a: a + 256].to(DEV)
+            ops.qknorm_rope_store_(part, qw.to(DEV), kw.to(DEV), 1e-6, pos[a: a + 256].to(DEV), cache.to(DEV), Hq, Hkv, D,
+                                   loc=loc[a: a + 256].to(DEV), k_cache=kv2[:, 0], v_cache=kv2[:, 1])
+            parts.append(part)
+        assert torch.equal(torch.cat(parts), qkv_d) and torch.equal(kv2, kvd)
     assert torch.equal(got[:, (Hq + Hkv) * D:], qkv[:, (Hq + Hkv) * D:])
     assert torch.equal(kvd[:, 1].cpu(), vc), "v rows must be copied bit exact"
     assert torch.equal(kvd[:, 0].cpu()[loc.long()].reshape(T, -1), got[:, Hq * D: (Hq + Hkv) * D]), "stored k = rotated k"
