@@ -85,22 +85,21 @@ class DeviceDecodeLoop:
     def _capture(self):
         # warm-up on a snapshot of the mutable state, restored afterwards: capture must not consume pages or tokens
         keep = [t.clone() for t in (self.seq_lens, self.last_slots, self.next_tokens, self.free_range, self.step_idx)]
-        rows = self.req_pool_indices.long()
-        r2t = self.mr.req_to_token_pool.req_to_token
+        # (the page-table entries and K/V slots the warm-up writes lie beyond the requests' lengths: never read)
         self._set_metadata(2)
         torch.cuda.synchronize()
         self._step()
         torch.cuda.synchronize()
-        self._restore(keep, rows, r2t)
+        self._restore(keep)
         g = torch.cuda.CUDAGraph()
         pool = self.mr.graph_runner.pool if self.mr.graph_runner is not None else None
         with torch.cuda.graph(g, pool=pool):
             self._step()
         self.graph = g
         torch.cuda.synchronize()
-        self._restore(keep, rows, r2t)
+        self._restore(keep)
 
-    def _restore(self, keep, rows, r2t):
+    def _restore(self, keep):
         for t, k in zip((self.seq_lens, self.last_slots, self.next_tokens, self.free_range, self.step_idx), keep):
             t.copy_(k)
         self.status.zero_()
