@@ -342,6 +342,12 @@ def decode_e2e(args, world, rank, barrier):
             ctx = 8192
             while ctx > 256 and bs * (ctx + 64) * per_token + weights > 0.85 * free:
                 ctx //= 2
+            if world > 1:  # every rank must build the same page tables: agree on the smallest choice
+                import torch.distributed as dist
+
+                c = torch.tensor([ctx], dtype=torch.int64, device="cuda")
+                dist.all_reduce(c, op=dist.ReduceOp.MIN)
+                ctx = int(c[0])
         info = {"model": "Qwen3-8B shape, random weights", "batch": bs, "ctx": ctx, "page_size": ps, "tp": world}
         use_graph = not args.e2e_eager
         try:
@@ -355,7 +361,7 @@ def decode_e2e(args, world, rank, barrier):
             mr, batch = decode_loop.build_decode_state(cfg, bs, ctx, ps, 2 * args.e2e_steps + 24, use_graph=False)
         dt = decode_loop.time_decode(mr, batch, args.e2e_steps, 4, barrier=barrier)
         if world > 1:
-            import torch.distributed as dist
+            import torch.distributed as dist  # noqa: F811
 
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
