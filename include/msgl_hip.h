@@ -179,6 +179,13 @@ int msgl_qknorm_rope_store(void* qkv, int64_t qkv_stride, const void* q_norm_w, 
 int msgl_argmax(const void* logits, int64_t row_stride, int elem_bytes, int32_t* out,
                 int bs, int vocab, void* stream);
 
+/* The same, also returning the winning value: out_val[b] = fp32(logits[b, out[b]]) (NULL = not wanted).
+ * With the vocabulary sharded over tensor-parallel ranks (lm_head rows, mini_sglang/layers/embed_head.py:56-80)
+ * every rank reduces its own shard and the ranks exchange bs (value, index) pairs instead of the
+ * [bs, vocab] logits that mini_sglang/layers/logits_processor.py:56-64 all-gathers. */
+int msgl_argmax_val(const void* logits, int64_t row_stride, int elem_bytes, int32_t* out, float* out_val,
+                    int bs, int vocab, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Decode-step preparation on the device.  Replaces BatchInfo.prepare_for_decode
  * (mini_sglang/managers/batch_info.py:247-302) together with the allocator call inside it

@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSGL_HIP_LIB", os.path.join(_HERE, "libmsgl_hip.so"))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # name -> (restype, argtypes); mirrors include/msgl_hip.h one to one
 SIGNATURES = {
@@ -47,6 +47,7 @@ SIGNATURES = {
          c_int, c_int, c_int, c_int, c_int, c_void_p],
     ),
     "msgl_argmax": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "msgl_argmax_val": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "msgl_prepare_decode": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,

@@ -321,7 +321,8 @@ __device__ __forceinline__ bool argmax_better(float v, int i, float bv, int bi) 
 
 // One 1024-thread block per row; 16 bytes per thread per step when the row is 16-byte aligned.
 template <typename T>
-__global__ __launch_bounds__(1024) void argmax_kernel(const T* logits, int64_t row_stride, int32_t* out, int vocab, int vec_ok) {
+__global__ __launch_bounds__(1024) void argmax_kernel(const T* logits, int64_t row_stride, int32_t* out, float* out_val, int vocab,
+                                                      int vec_ok) {
     __shared__ float bv[16];
     __shared__ int bi[16];
     constexpr int VEC = 16 / sizeof(T);
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const T* logits, int64_t r
                 besti = bi[w];
             }
         out[blockIdx.x] = besti == 0x7fffffff ? 0 : besti;
+        if (out_val != nullptr) out_val[blockIdx.x] = best;
     }
 }
 
@@ -531,8 +533,8 @@ extern "C" int msgl_qknorm_rope_store(void* qkv, int64_t qkv_stride, const void*
     return check_launch("qknorm_rope_store");
 }
 
-extern "C" int msgl_argmax(const void* logits, int64_t row_stride, int elem_bytes, int32_t* out, int bs, int vocab,
-                           void* stream) {
+extern "C" int msgl_argmax_val(const void* logits, int64_t row_stride, int elem_bytes, int32_t* out, float* out_val, int bs,
+                               int vocab, void* stream) {
     if (bs == 0) return MSGL_OK;
     MSGL_REQUIRE(bs > 0 && vocab > 0 && logits && out, "msgl_argmax: bs=%d vocab=%d or null pointer", bs, vocab);
     MSGL_REQUIRE(elem_bytes == 2 || elem_bytes == 4, "msgl_argmax: elem_bytes=%d (2 = bf16, 4 = fp32)", elem_bytes);
@@ -540,9 +542,14 @@ extern "C" int msgl_argmax(const void* logits, int64_t row_stride, int elem_byte
     const int vec_ok = aligned16(logits) && (row_stride * elem_bytes) % 16 == 0;
     if (elem_bytes == 2)
         hipLaunchKernelGGL((argmax_kernel<uint16_t>), dim3(bs), dim3(1024), 0, st, static_cast<const uint16_t*>(logits),
-                           row_stride, out, vocab, vec_ok);
+                           row_stride, out, out_val, vocab, vec_ok);
     else
         hipLaunchKernelGGL((argmax_kernel<float>), dim3(bs), dim3(1024), 0, st, static_cast<const float*>(logits), row_stride,
-                           out, vocab, vec_ok);
+                           out, out_val, vocab, vec_ok);
     return check_launch("argmax");
+}
+
+extern "C" int msgl_argmax(const void* logits, int64_t row_stride, int elem_bytes, int32_t* out, int bs, int vocab,
+                           void* stream) {
+    return msgl_argmax_val(logits, row_stride, elem_bytes, out, nullptr, bs, vocab, stream);
 }

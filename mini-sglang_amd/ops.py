@@ -277,15 +277,18 @@ def qknorm_rope_store_(qkv: torch.Tensor, q_weight: torch.Tensor, k_weight: torc
         cs, T, Hq, Hkv, head_dim, 0 if reference_rounding else 1, _stream()))
 
 
-def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Greedy token per row of logits [bs, vocab] (bf16 or fp32); int32 [bs]."""
+def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None, return_values: bool = False):
+    """Greedy token per row of logits [bs, vocab] (bf16 or fp32); int32 [bs].  With return_values also the
+    winning logit as fp32 [bs] (what tensor-parallel ranks exchange instead of their logits shards)."""
     _need(logits.is_cuda and logits.dtype in (torch.bfloat16, torch.float32), "logits must be bf16 or fp32 on the GPU")
     bs, vocab, rs = _rows_view(logits, "logits")
     if out is None:
         out = torch.empty(bs, dtype=torch.int32, device=logits.device)
     _dev_i32(out, "out")
-    _check(_lib.msgl_argmax(logits.data_ptr(), rs, logits.element_size(), out.data_ptr(), bs, vocab, _stream()))
-    return out
+    vals = torch.empty(bs, dtype=torch.float32, device=logits.device) if return_values else None
+    _check(_lib.msgl_argmax_val(logits.data_ptr(), rs, logits.element_size(), out.data_ptr(),
+                                vals.data_ptr() if vals is not None else None, bs, vocab, _stream()))
+    return (out, vals) if return_values else out
 
 
 def prepare_decode(req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, last_slots: torch.Tensor, free_pages: torch.Tensor,

@@ -68,8 +68,9 @@ class DeviceDecodeLoop:
         ops.prepare_decode(self.req_pool_indices, self.seq_lens, self.last_slots, self.free_pages, self.free_range,
                            mr.req_to_token_pool.req_to_token, self.positions, self.out_cache_loc, self.status, mr.page_size,
                            next_tokens=self.next_tokens, input_ids=self.input_ids)
-        logits = mr.model(self.input_ids, self.positions, self.static_batch)
-        ops.argmax(logits, out=self.next_tokens)
+        # greedy sampling on the vocabulary shard of each rank; the ranks exchange (value, index) pairs, not logits
+        mr.model.forward_greedy(self.input_ids, self.positions, self.static_batch,
+                                lambda lg: ops.argmax(lg, return_values=True), out=self.next_tokens)
         self.token_log.index_copy_(0, self.step_idx, self.next_tokens.view(1, -1))
         self.step_idx.add_(1)
 

@@ -408,6 +408,10 @@ def test_argmax():
     for t in (logits, logits.float()):
         got = ops.argmax(t.to(DEV)).cpu()
         assert torch.equal(got, orc.argmax_ref(t)), (got, orc.argmax_ref(t))
+        idx, val = ops.argmax(t.to(DEV), return_values=True)
+        want = t.float().gather(1, orc.argmax_ref(t).long()[:, None])[:, 0]
+        assert torch.equal(idx.cpu(), got)
+        assert torch.equal(val.cpu().nan_to_num(nan=123.0), want.nan_to_num(nan=123.0)), "the winning logit itself, bit for bit"
 
 
 # ------------------------------------------------------------------------------------------------ batch preparation

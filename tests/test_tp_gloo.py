@@ -48,11 +48,23 @@ def _worker(rank, world, port, name, steps, out):
         lg, _ = mr.forward_generate(batch)
         tops.append(lg.float().max(dim=-1).values)
         mr.process_result(batch, lg)
+        def cpu_argmax(local):  # stands in for the HIP argmax: (index, value) of this rank's vocabulary shard
+            i = local.float().argmax(dim=-1)
+            return i.to(torch.int32), local.float().gather(1, i[:, None])[:, 0]
+
         for _ in range(steps - 1):
             batch.prepare_for_decode()
             lg, _ = mr.forward_generate(batch)
             tops.append(lg.float().max(dim=-1).values)
+            # sampling on the shards (pairs exchanged instead of logits) picks the same tokens as the gathered logits
+            sharded = mr.model.forward_greedy(batch.input_ids, batch.positions, batch, cpu_argmax)
+            assert torch.equal(sharded.long(), lg.float().argmax(dim=-1))
             mr.process_result(batch, lg)
+        # ties between shards go to the lower token id, NaN counts as the maximum
+        from mini_sglang_amd.runtime.qwen3 import pick_sharded_argmax
+        val = torch.tensor([1.0, 2.0 + rank, 5.0 - rank, float("nan") if rank == 1 else 9.0, 3.0])
+        idx = torch.tensor([7, 3, 4, 2, 0], dtype=torch.int32)
+        assert pick_sharded_argmax(idx, val, 100).tolist() == [7, 103, 4, 102, 0]
         toks = torch.tensor([r.token_ids[len(p):] for r, p in zip(reqs, prompts)], dtype=torch.int32)
         # every rank must hold the same logits after the all-gather, hence the same tokens
         gathered = [torch.empty_like(toks) for _ in range(world)]
