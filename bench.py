@@ -177,6 +177,25 @@ def main():
         },
     }
 
+    # an on-box yardstick beside the spec peak: a large device-to-device copy (reads + writes both counted)
+    try:
+        src = torch.empty(1 << 31, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        for _ in range(2):
+            dst.copy_(src)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 2 * src.numel() * 5 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        result["roofline"]["measured_copy_GBps"] = round(copy_gbps, 1)
+        result["roofline"]["frac_of_measured_copy"] = round(achieved / copy_gbps, 4)
+        del src, dst
+    except Exception as e:
+        result["roofline"]["measured_copy_error"] = f"{type(e).__name__}: {e}"[:120]
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(pools[0], qs[0], r2t, S, ps, Hq, Hkv, D, scale, args.cpu_seconds)
     if args.layout == "interleaved" and bs == 256 and S == 8192 and ps == 16 and Hq == 32 and Hkv == 8:
