@@ -483,6 +483,40 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_merge_kernel(DecodeParam
     }
 }
 
+// The same merge for at most 64 splits: one WAVE per (request, query head), no LDS and no barrier — lane s
+// holds split s's (max, sum) pair, the weights stay in registers and are broadcast with a lane read.
+__global__ __launch_bounds__(256) void paged_decode_merge_small_kernel(DecodeParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);  // (request, query head)
+    if (row >= p.bs * p.Hq) return;
+    const int b = row / p.Hq;
+    const int hq = row - b * p.Hq;
+    const int S = p.seq_lens[b];
+    const int chunk = split_chunk(p);
+    const int nsplit = min((S + chunk - 1) / chunk, p.max_splits);
+    if (nsplit <= 1) return;  // written directly by the main kernel
+    const int64_t row0 = ((int64_t)b * p.max_splits) * p.Hq + hq;
+    const float2 ml = lane < nsplit ? *reinterpret_cast<const float2*>(p.ws_ml + (row0 + (int64_t)lane * p.Hq) * 2)
+                                    : make_float2(kNegBig, 0.f);
+    float M = ml.x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off));
+    const float w = lane < nsplit ? fast_exp2(ml.x - M) : 0.f;
+    const float L = wave_sum(w * ml.y);
+    const int d = lane * 2;
+    const float* src = p.ws_o + row0 * kD + d;
+    const int64_t step = (int64_t)p.Hq * kD;
+    float o0 = 0.f, o1 = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float2 o = *reinterpret_cast<const float2*>(src + (int64_t)s * step);
+        const float f = __shfl(w, s);
+        o0 = fmaf(f, o.x, o0);
+        o1 = fmaf(f, o.y, o1);
+    }
+    const float inv = 1.0f / L;
+    *reinterpret_cast<uint32_t*>(p.out + (int64_t)b * p.out_stride + hq * kD + d) = pack_bf16(o0 * inv, o1 * inv);
+}
+
 template <int G, int HPB>
 static int launch_decode(const DecodeParams& p, int page_size, hipStream_t stream) {
     const dim3 grid(p.bs * p.max_splits), block(kWaves * 64);
@@ -494,8 +528,8 @@ static int launch_decode(const DecodeParams& p, int page_size, hipStream_t strea
     int rc = check_launch("paged_decode_kernel");
     if (rc) return rc;
     if (p.max_splits > 1) {
-        if (p.max_splits <= 16)  // few splits: 4 waves already cover them
-            hipLaunchKernelGGL(paged_decode_merge_kernel<4>, dim3(p.bs * p.Hq), dim3(256), 0, stream, p);
+        if (p.max_splits <= 16)  // few splits: a wave per row, four rows per group
+            hipLaunchKernelGGL(paged_decode_merge_small_kernel, dim3((p.bs * p.Hq + 3) / 4), dim3(256), 0, stream, p);
         else
             hipLaunchKernelGGL(paged_decode_merge_kernel<16>, dim3(p.bs * p.Hq), dim3(1024), 0, stream, p);
         rc = check_launch("paged_decode_merge_kernel");
