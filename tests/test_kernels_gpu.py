@@ -242,6 +242,15 @@ def test_extend_long_prefix(heads_per_group, monkeypatch):
     check_extend(case, run_extend(case, 16))
 
 
+@pytest.mark.parametrize("heads_per_group", [1, 2])
+def test_extend_few_queries_on_long_unaligned_prefixes(heads_per_group, monkeypatch):
+    """Decode-like calls through the extend entry point (chunked prefill tails): 1-5 new tokens on prefixes that are
+    not multiples of the 64-key tile, so almost every wave of the work group has nothing to do."""
+    monkeypatch.setenv("MSGL_EXTEND_NH", str(heads_per_group))
+    case = build_extend_case(8, 2, 1, [4097, 33, 63, 64, 0], [1, 5, 2, 1, 1], seed=41)
+    check_extend(case, run_extend(case, 1))
+
+
 def test_extend_full_size_rows_match_decode_and_fp64():
     """A 4096-token prompt on top of a 1024-token cached prefix, Qwen3-8B heads (too large for the CPU oracle as
     a whole): sampled query rows must equal what the decode kernel returns for the same query over the same
