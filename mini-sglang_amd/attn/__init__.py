@@ -1,3 +1,3 @@
-from .attn_backend import AttentionBackend
+from .backend_api import AttentionBackend
 
 __all__ = ["AttentionBackend"]

@@ -21,7 +21,7 @@ from typing import Dict, Optional
 import torch
 
 from .. import ops
-from .attn_backend import AttentionBackend
+from .backend_api import AttentionBackend
 
 
 @dataclass

@@ -1,6 +1,6 @@
 """Layer modules with the reference's signatures, backed by HIP kernels only."""
 from .activation import SiluAndMul
-from .attention import Attention
+from .attn_layer import Attention
 from .layernorm import RMSNorm
 from .rotary_embedding import RotaryEmbedding, get_rope
 from ..ops import qknorm_rope_store_ as _qknorm_rope_store_

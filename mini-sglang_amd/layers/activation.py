@@ -1,4 +1,6 @@
-"""SiluAndMul with the reference's module signature (mini_sglang/layers/activation.py:6-14)."""
+"""Gated SiLU as a module with the reference's signature (mini_sglang/layers/activation.py:6-14): the input's last
+dimension holds gate and up projections side by side, the output is ``silu(gate) * up`` at half the width.  One HIP
+kernel (msgl_silu_and_mul), one pass over the data; there is no torch fallback."""
 from __future__ import annotations
 
 import torch
@@ -8,9 +10,9 @@ from .. import ops
 
 
 class SiluAndMul(nn.Module):
-    def __init__(self) -> None:
-        super().__init__()
-
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])
-        return ops.silu_and_mul(x2).view(*x.shape[:-1], x.shape[-1] // 2)
+        width = x.shape[-1]
+        if width % 2:
+            raise ValueError(f"last dimension {width} cannot be split into gate and up halves")
+        rows = x if x.dim() == 2 else x.reshape(-1, width)
+        return ops.silu_and_mul(rows).view(*x.shape[:-1], width // 2)
