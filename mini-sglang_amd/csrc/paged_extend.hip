@@ -36,8 +36,7 @@ constexpr int kKRow = 256;        // bytes per K row in LDS (swizzled 16-byte ch
 constexpr int kVRow = 320;        // bytes per V row in LDS (padded: conflict-free transposed reads)
 constexpr int kKBytes = kBN * kKRow;
 constexpr int kTileBytes = kBN * kKRow + kBN * kVRow;
-constexpr int kStages = 3;
-constexpr int kExtendLds = kStages * kTileBytes;
+
 constexpr float kNegBigE = -1.0e30f;
 
 struct ExtendParams {
@@ -131,11 +130,15 @@ __device__ __forceinline__ void stage_write(char* tile, int skey, int c16, const
 
 constexpr int SG_VALU = 0x002, SG_MFMA = 0x008, SG_VMEMREAD = 0x020, SG_DSREAD = 0x100, SG_DSWRITE = 0x200, SG_TRANS = 0x400;
 
-template <int NH>
+// ST = LDS ring depth.  3: one barrier per tile, 108 KiB, one work group per CU — the throughput form.
+// 2: the ring slot of tile t+1 is only free once every wave has finished tile t-1, so the write sits between two
+// barriers; 72 KiB lets two 4-wave groups share a CU, which hides the serial start-up (page table -> rows ->
+// LDS -> first S^T) that dominates when a request has only a handful of key tiles.
+template <int NH, int ST>
 __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams p) {
     constexpr int KPT = 4 / NH;          // keys staged per thread and tile
     constexpr int KSTEP = 16 * NH;       // distance between a thread's staged keys
-    extern __shared__ __attribute__((aligned(256))) char lds[];
+    extern __shared__ __attribute__((aligned(256))) char lds[];  // ST * kTileBytes
 
     // Block order: the last (heaviest under the causal mask) query tile of every request and head first,
     // so the long blocks start early and the short ones fill the tail.  The kv head varies fastest: with
@@ -295,16 +298,18 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
     const int skey = tid >> 4;
     const uint16_t* kcol = p.kc + hk * kHD + c16 * 8;
     const uint16_t* vcol = p.vc + hk * kHD + c16 * 8;
-    // tiles 0 and 1 go to ring slots 0 and 1 before the first barrier, tile 2 waits in registers
+    // tile 0 (and, with three slots, tile 1) go into the ring before the first barrier, the next tile waits in registers
     StageSlots<KPT> slots = stage_slots<KPT, KSTEP>(r2t_row, 0, skey, kv_len);
     StageRegs<KPT> stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
     slots = stage_slots<KPT, KSTEP>(r2t_row, min(1, nkt - 1), skey, kv_len);
     stage_write<KPT, KSTEP>(lds, skey, c16, stg);
     stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);  // (past the last tile: harmless re-read of it)
     slots = stage_slots<KPT, KSTEP>(r2t_row, min(2, nkt - 1), skey, kv_len);
-    stage_write<KPT, KSTEP>(lds + kTileBytes, skey, c16, stg);
-    stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
-    slots = stage_slots<KPT, KSTEP>(r2t_row, min(3, nkt - 1), skey, kv_len);
+    if constexpr (ST == 3) {
+        stage_write<KPT, KSTEP>(lds + kTileBytes, skey, c16, stg);
+        stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
+        slots = stage_slots<KPT, KSTEP>(r2t_row, min(3, nkt - 1), skey, kv_len);
+    }
     __syncthreads();
     if (my_nkt > 0) {
         f32x16_t s0, s1;
@@ -315,7 +320,22 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
     int cur = 0, nxt = kTileBytes, nn = 2 * kTileBytes;  // LDS offsets of tiles t, t+1, t+2 in the ring
     auto advance_ring = [&]() {
         const int c = cur;
-        cur = nxt, nxt = nn, nn = c;
+        if constexpr (ST == 3) cur = nxt, nxt = nn, nn = c;
+        else cur = nxt, nxt = c;
+    };
+    // staging at the top of iteration t: three slots -> tile t+2 into the slot tile t-1 was read from, after the
+    // barrier and beside the matrix work; two slots -> tile t+1 between two barriers
+    auto stage_step = [&](int t) {
+        __syncthreads();
+        if constexpr (ST == 2) {
+            stage_write<KPT, KSTEP>(lds + nxt, skey, c16, stg);
+            __syncthreads();
+        }
+    };
+    auto stage_refill = [&](int t) {
+        if constexpr (ST == 3) stage_write<KPT, KSTEP>(lds + nn, skey, c16, stg);
+        stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
+        slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + ST + 1, nkt - 1), skey, kv_len);
     };
     // Every iteration of either loop below: one barrier (tile t+1, written during iteration t-1, becomes
     // visible and the ring slot tile t-1 was read from becomes free); tile t+2 goes from registers into that
@@ -325,11 +345,9 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
     int t = 0;
     // ---- steady state: tile t+1 is visible to every row of the wave ----
     for (; t + 1 < full_nkt; ++t) {
-        __syncthreads();
+        stage_step(t);
         rescale_o(alpha_pend);  // a branch of its own, ahead of the block below, so that nothing of that block sinks behind it
-        stage_write<KPT, KSTEP>(lds + nn, skey, c16, stg);
-        stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);  // tile t+3
-        slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + 4, nkt - 1), skey, kv_len);
+        stage_refill(t);
 
         // S^T of tile t+1 (reads two k-steps ahead of the matrix instructions), the row sum of tile t beside it
         f32x16_t s0, s1;
@@ -418,10 +436,8 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
     }
     // ---- the diagonal tiles, then the tiles only other waves of the work group still need ----
     for (; t < nkt; ++t) {
-        __syncthreads();
-        stage_write<KPT, KSTEP>(lds + nn, skey, c16, stg);  // past the last tile: a copy of it into a free slot
-        stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
-        slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + 4, nkt - 1), skey, kv_len);
+        stage_step(t);
+        stage_refill(t);  // past the last tile: a copy of it into a free slot
         if (t < my_nkt) {
             rescale_o(alpha_pend);
             l = l * alpha_pend + sum_tile();
@@ -454,18 +470,19 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
         }
 }
 
-template <int NH>
+template <int NH, int ST>
 static int launch_extend(const ExtendParams& p, int64_t blocks, hipStream_t stream) {
+    constexpr int kLds = ST * kTileBytes;
     static bool configured = false;  // the ring is larger than the 64 KiB a kernel gets by default
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(paged_extend_kernel<NH>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kExtendLds) != hipSuccess) {
-            set_error("msgl_paged_extend: cannot reserve %d bytes of LDS", kExtendLds);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(paged_extend_kernel<NH, ST>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kLds) != hipSuccess) {
+            set_error("msgl_paged_extend: cannot reserve %d bytes of LDS", kLds);
             return MSGL_E_LAUNCH;
         }
         configured = true;
     }
-    hipLaunchKernelGGL(paged_extend_kernel<NH>, dim3((unsigned)blocks), dim3(256 * NH), kExtendLds, stream, p);
+    hipLaunchKernelGGL((paged_extend_kernel<NH, ST>), dim3((unsigned)blocks), dim3(256 * NH), kLds, stream, p);
     return check_launch("paged_extend_kernel");
 }
 
@@ -516,5 +533,9 @@ extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_
     else if (nh == 2 && (int64_t)bs * p.tiles_per_req * (Hq / 2) <= device_cus()) nh = 1;
     const int64_t gx = (int64_t)bs * p.tiles_per_req * (Hq / nh);
     MSGL_REQUIRE(gx <= 0x7fffffff, "msgl_paged_extend: grid too large");
-    return nh == 2 ? launch_extend<2>(p, gx, static_cast<hipStream_t>(stream)) : launch_extend<1>(p, gx, static_cast<hipStream_t>(stream));
+    const char* se = getenv("MSGL_EXTEND_ST");
+    const bool two_slots = se ? atoi(se) == 2 : false;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (two_slots) return launch_extend<1, 2>(p, (int64_t)bs * p.tiles_per_req * Hq, st);
+    return nh == 2 ? launch_extend<2, 3>(p, gx, st) : launch_extend<1, 3>(p, gx, st);
 }
