@@ -112,6 +112,11 @@ int msgl_paged_decode(const void* q, int64_t q_stride,
  * q / out: [sum Sq, Hq, D] bf16 (token stride q_stride / out_stride).
  * cu_seqlens_q: int32 [bs+1] exclusive prefix sum of the per-request query counts.
  * prefix_lens: int32 [bs].  max_seqlen_q: upper bound on Sq_b (sizes the grid).
+ * max_seqlen_k: upper bound on prefix_lens[b] + Sq_b, the max_seq_len_k of the
+ * FA3 metadata (fa3_attn_backend.py:43-82), or 0 when the caller does not know
+ * it.  plan: NULL, or the launch order msgl_extend_plan wrote for these very
+ * cu_seqlens_q / prefix_lens / max_seqlen_q.  Both only steer scheduling (kernel
+ * variant, block order); the output does not depend on them.
  * The new tokens' K/V must already be in the pool (msgl_store_kv first), as in
  * torch_attn_backend.py:195-196.
  * ------------------------------------------------------------------------- */
@@ -121,8 +126,23 @@ int msgl_paged_extend(const void* q, int64_t q_stride,
                       const int32_t* req_pool_indices, const int32_t* cu_seqlens_q,
                       const int32_t* prefix_lens,
                       void* out, int64_t out_stride,
-                      int bs, int max_seqlen_q, int Hq, int Hkv, int D, int page_size,
+                      int bs, int max_seqlen_q, int max_seqlen_k, const int32_t* plan,
+                      int Hq, int Hkv, int D, int page_size,
                       float scale, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Launch order for msgl_paged_extend on a ragged batch, computed on the device
+ * once per forward pass and reused by every layer: the place the FA3 backend
+ * builds its per-batch metadata (fa3_attn_backend.py:43-82, init_forward_metadata).
+ * Work items (request b, 128-row query tile qt), encoded b * tiles + qt with
+ * tiles = ceil(max_seqlen_q / 128), are sorted by their number of 64-key tiles
+ * (prefix included), longest first; plan has msgl_extend_plan_items(bs,
+ * max_seqlen_q) int32 entries, the unused tail is -1.  The order among items of
+ * equal length is unspecified.
+ * ------------------------------------------------------------------------- */
+int64_t msgl_extend_plan_items(int bs, int max_seqlen_q);
+int msgl_extend_plan(const int32_t* cu_seqlens_q, const int32_t* prefix_lens,
+                     int bs, int max_seqlen_q, int32_t* plan, void* stream);
 
 /* ---------------------------------------------------------------------------
  * RMSNorm.  Replaces RMSNorm.forward(x) (mini_sglang/layers/layernorm.py:39-50,

@@ -34,6 +34,8 @@ class HipAttnMetadata:
     # extend
     cu_seqlens_q: Optional[torch.Tensor] = None
     max_seqlen_q: int = 0
+    max_seqlen_k: int = 0
+    extend_plan: Optional[torch.Tensor] = None  # launch order of the (request, query tile) items, longest first
 
 
 def splits_for_batch(bs: int) -> int:
@@ -86,7 +88,10 @@ class HipAttnBackend(AttentionBackend):
             md.reuse_lens = getattr(batch, "shared_prefix_lens", None)
         else:
             md.max_seqlen_q = int(batch.input_seq_lens_max)
+            md.max_seqlen_k = int(batch.seq_lens_cpu.max())
             md.cu_seqlens_q = torch.nn.functional.pad(torch.cumsum(batch.input_seq_lens, dim=0, dtype=torch.int32), (1, 0))
+            if bs > 1:  # a single request's tiles are already launched longest first
+                md.extend_plan = ops.extend_plan(md.cu_seqlens_q, batch.prefix_seq_lens, md.max_seqlen_q)
         self.forward_metadata = md
 
     # ------------------------------------------------------------------ forward
@@ -98,7 +103,8 @@ class HipAttnBackend(AttentionBackend):
         T = q.shape[0]
         o = ops.paged_extend(
             _as_heads(q, layer.num_heads, layer.head_dim), k_cache, v_cache, self.req_to_token_pool.req_to_token,
-            batch.req_pool_indices, md.cu_seqlens_q, batch.prefix_seq_lens, md.max_seqlen_q, layer.scale, self.page_size)
+            batch.req_pool_indices, md.cu_seqlens_q, batch.prefix_seq_lens, md.max_seqlen_q, layer.scale, self.page_size,
+            max_seqlen_k=md.max_seqlen_k, plan=md.extend_plan)
         return o.view(T, layer.num_heads * layer.head_dim)
 
     def forward_decode(self, q, k, v, layer, batch, save_kv_cache: bool = True):

@@ -38,6 +38,7 @@ constexpr int kKBytes = kBN * kKRow;
 constexpr int kTileBytes = kBN * kKRow + kBN * kVRow;
 
 constexpr float kNegBigE = -1.0e30f;
+constexpr int kShortKv = 768;     // longest request (prefix + new tokens) that still takes the two-slot kernel
 
 struct ExtendParams {
     const uint16_t* q;
@@ -57,6 +58,7 @@ struct ExtendParams {
     int hkv;
     int group;  // query heads per kv head
     float scale_log2e;
+    const int32_t* plan;  // optional: (request, query tile) items in launch order, see extend_plan_kernel
 };
 
 __device__ __forceinline__ bf16x8_t as_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
@@ -147,8 +149,14 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
     const int idx = blockIdx.x;
     const int hk = idx % p.hkv;
     const int hs = (idx / p.hkv) % hsets;
-    const int b = (idx / (p.hkv * hsets)) % p.bs;
-    const int qt = p.tiles_per_req - 1 - idx / (p.hkv * hsets * p.bs);
+    int b = (idx / (p.hkv * hsets)) % p.bs;
+    int qt = p.tiles_per_req - 1 - idx / (p.hkv * hsets * p.bs);
+    if (p.plan) {  // ragged batches: items sorted by their number of key tiles, longest first
+        const int item = p.plan[idx / (p.hkv * hsets)];
+        if (item < 0) return;
+        b = item / p.tiles_per_req;
+        qt = item - b * p.tiles_per_req;
+    }
     const int q0 = p.cu_q[b];
     const int Sq = p.cu_q[b + 1] - q0;
     if (qt * kBM >= Sq) return;
@@ -470,6 +478,57 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
         }
 }
 
+// Launch order for a ragged batch.  Item i = b * tiles_per_req + qt stands for query rows [128 qt, 128 qt + 128)
+// of request b; its cost is its number of 64-key tiles (prefix included), which the host cannot know without
+// reading the lengths back.  One work group: counting sort of the items by that number, longest first, so the
+// hardware's in-order dispatch becomes longest-processing-time-first scheduling; items past a request's
+// length are dropped and the rest of `plan` is filled with -1.  Items of equal cost land in arbitrary order
+// (LDS atomics); the attention output does not depend on the order.
+constexpr int kPlanBins = 2048;
+__global__ __launch_bounds__(1024) void extend_plan_kernel(const int32_t* __restrict__ cu_q, const int32_t* __restrict__ prefix, int bs,
+                                                           int tiles_per_req, int32_t* __restrict__ plan) {
+    __shared__ int bins[kPlanBins];   // bin r holds the items with kPlanBins - 1 - r key tiles (clamped): ascending r = descending cost
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int n = bs * tiles_per_req;
+    for (int i = tid; i < kPlanBins; i += 1024) bins[i] = 0;
+    __syncthreads();
+    auto bin_of = [&](int i) -> int {
+        const int b = i / tiles_per_req, qt = i - b * tiles_per_req;
+        const int Sq = cu_q[b + 1] - cu_q[b];
+        if (qt * kBM >= Sq) return -1;
+        const int pre = prefix[b];
+        const int kv_len = min(pre + Sq, pre + qt * kBM + kBM);
+        return kPlanBins - 1 - min((kv_len + kBN - 1) / kBN, kPlanBins - 1);
+    };
+    for (int i = tid; i < n; i += 1024) {
+        const int r = bin_of(i);
+        if (r >= 0) atomicAdd(&bins[r], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the bins: two per thread, then Hillis-Steele over the 1024 partial sums
+    const int c0 = bins[2 * tid], c1 = bins[2 * tid + 1];
+    part[tid] = c0 + c1;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int add = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    const int before = part[tid] - (c0 + c1);
+    const int total = part[1023];
+    __syncthreads();
+    bins[2 * tid] = before;
+    bins[2 * tid + 1] = before + c0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int r = bin_of(i);
+        if (r >= 0) plan[atomicAdd(&bins[r], 1)] = i;
+    }
+    for (int i = total + tid; i < n; i += 1024) plan[i] = -1;
+}
+
 template <int NH, int ST>
 static int launch_extend(const ExtendParams& p, int64_t blocks, hipStream_t stream) {
     constexpr int kLds = ST * kTileBytes;
@@ -493,11 +552,12 @@ using namespace msgl;
 extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
                                  int64_t cache_stride, const int32_t* req_to_token, int64_t r2t_stride,
                                  const int32_t* req_pool_indices, const int32_t* cu_seqlens_q, const int32_t* prefix_lens,
-                                 void* out, int64_t out_stride, int bs, int max_seqlen_q, int Hq, int Hkv, int D,
-                                 int page_size, float scale, void* stream) {
+                                 void* out, int64_t out_stride, int bs, int max_seqlen_q, int max_seqlen_k, const int32_t* plan,
+                                 int Hq, int Hkv, int D, int page_size, float scale, void* stream) {
     (void)page_size;  // the table is read per token, which is valid for every page size
     if (bs == 0 || max_seqlen_q == 0) return MSGL_OK;
-    MSGL_REQUIRE(bs > 0 && max_seqlen_q > 0, "msgl_paged_extend: bs=%d max_seqlen_q=%d", bs, max_seqlen_q);
+    MSGL_REQUIRE(bs > 0 && max_seqlen_q > 0 && max_seqlen_k >= 0, "msgl_paged_extend: bs=%d max_seqlen_q=%d max_seqlen_k=%d", bs,
+                 max_seqlen_q, max_seqlen_k);
     MSGL_REQUIRE(D == kHD, "msgl_paged_extend: head dim %d unsupported (128 only)", D);
     MSGL_REQUIRE(Hkv > 0 && Hq > 0 && Hq % Hkv == 0 && Hq <= 65535, "msgl_paged_extend: Hq=%d Hkv=%d", Hq, Hkv);
     MSGL_REQUIRE(q && k_cache && v_cache && req_to_token && req_pool_indices && cu_seqlens_q && prefix_lens && out,
@@ -527,15 +587,39 @@ extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_
     p.hkv = Hkv;
     p.group = Hq / Hkv;
     p.scale_log2e = scale * 1.4426950408889634f;
+    p.plan = plan;
     // query heads per work group: 2 share the staged K/V tile; 1 when that would leave compute units without a block
     int nh = (p.group % 2 == 0) ? 2 : 1;
     if (const char* e = getenv("MSGL_EXTEND_NH")) nh = (atoi(e) == 2 && p.group % 2 == 0) ? 2 : 1;
     else if (nh == 2 && (int64_t)bs * p.tiles_per_req * (Hq / 2) <= device_cus()) nh = 1;
     const int64_t gx = (int64_t)bs * p.tiles_per_req * (Hq / nh);
     MSGL_REQUIRE(gx <= 0x7fffffff, "msgl_paged_extend: grid too large");
+    // Requests of at most a dozen key tiles never reach the steady state the three-slot ring is built for; two
+    // work groups per CU (two-slot ring, one head per group) overlap their start-up phases instead.
     const char* se = getenv("MSGL_EXTEND_ST");
-    const bool two_slots = se ? atoi(se) == 2 : false;
+    const bool two_slots = se ? atoi(se) == 2 : (max_seqlen_k > 0 && max_seqlen_k <= kShortKv);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (two_slots) return launch_extend<1, 2>(p, (int64_t)bs * p.tiles_per_req * Hq, st);
+    if (two_slots) {
+        const int64_t g1 = (int64_t)bs * p.tiles_per_req * Hq;
+        MSGL_REQUIRE(g1 <= 0x7fffffff, "msgl_paged_extend: grid too large");
+        return launch_extend<1, 2>(p, g1, st);
+    }
     return nh == 2 ? launch_extend<2, 3>(p, gx, st) : launch_extend<1, 3>(p, gx, st);
+}
+
+extern "C" int64_t msgl_extend_plan_items(int bs, int max_seqlen_q) {
+    if (bs <= 0 || max_seqlen_q <= 0) return 0;
+    return (int64_t)bs * ((max_seqlen_q + kBM - 1) / kBM);
+}
+
+extern "C" int msgl_extend_plan(const int32_t* cu_seqlens_q, const int32_t* prefix_lens, int bs, int max_seqlen_q, int32_t* plan,
+                                void* stream) {
+    if (bs == 0 || max_seqlen_q == 0) return MSGL_OK;
+    MSGL_REQUIRE(bs > 0 && max_seqlen_q > 0, "msgl_extend_plan: bs=%d max_seqlen_q=%d", bs, max_seqlen_q);
+    MSGL_REQUIRE(cu_seqlens_q && prefix_lens && plan, "msgl_extend_plan: null pointer argument");
+    const int64_t n = msgl_extend_plan_items(bs, max_seqlen_q);
+    MSGL_REQUIRE(n <= 0x7fffffff, "msgl_extend_plan: %lld items", (long long)n);
+    hipLaunchKernelGGL(extend_plan_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), cu_seqlens_q, prefix_lens, bs,
+                       (max_seqlen_q + kBM - 1) / kBM, plan);
+    return check_launch("extend_plan_kernel");
 }

@@ -178,8 +178,12 @@ def paged_extend(
     page_size: int,
     *,
     out: Optional[torch.Tensor] = None,
+    max_seqlen_k: int = 0,
+    plan: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
-    """Extend attention for packed q [sum Sq, Hq, D]; K/V of the new tokens must already be stored."""
+    """Extend attention for packed q [sum Sq, Hq, D]; K/V of the new tokens must already be stored.
+    `max_seqlen_k` (longest prefix + new tokens, 0 = unknown) and `plan` (from extend_plan, same batch) only
+    steer scheduling; the output does not depend on them."""
     _dev_bf16(q, "q")
     _dev_i32(req_pool_indices, "req_pool_indices"), _dev_i32(cu_seqlens_q, "cu_seqlens_q"), _dev_i32(prefix_lens, "prefix_lens")
     _need(q.dim() == 3 and q.stride(2) == 1 and q.stride(1) == q.shape[2], "q must be [T, Hq, D] with dense heads")
@@ -198,10 +202,35 @@ def paged_extend(
         _need(out.shape == q.shape and out.stride(2) == 1 and out.stride(1) == D, "out must match q's layout")
     qs = q.stride(0) if T > 1 else Hq * D
     os_ = out.stride(0) if T > 1 else Hq * D
+    if plan is not None:
+        _dev_i32(plan, "plan")
+        _need(plan.numel() == extend_plan_items(bs, int(max_seqlen_q)), "plan was made for another bs / max_seqlen_q")
     _check(_lib.msgl_paged_extend(
         q.data_ptr(), qs, k_cache.data_ptr(), v_cache.data_ptr(), cs,
         req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(), cu_seqlens_q.data_ptr(),
-        prefix_lens.data_ptr(), out.data_ptr(), os_, bs, int(max_seqlen_q), Hq, Hkv, D, page_size, float(scale), _stream()))
+        prefix_lens.data_ptr(), out.data_ptr(), os_, bs, int(max_seqlen_q), int(max_seqlen_k),
+        plan.data_ptr() if plan is not None else None, Hq, Hkv, D, page_size, float(scale), _stream()))
+    return out
+
+
+def extend_plan_items(bs: int, max_seqlen_q: int) -> int:
+    return int(_lib.msgl_extend_plan_items(int(bs), int(max_seqlen_q)))
+
+
+def extend_plan(cu_seqlens_q: torch.Tensor, prefix_lens: torch.Tensor, max_seqlen_q: int,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Launch order of paged_extend's work items for this batch, longest (most key tiles) first; computed on
+    the device, so the lengths are not read back.  One call per forward pass serves every layer."""
+    _dev_i32(cu_seqlens_q, "cu_seqlens_q"), _dev_i32(prefix_lens, "prefix_lens")
+    bs = prefix_lens.numel()
+    _need(cu_seqlens_q.numel() == bs + 1, "cu_seqlens_q needs bs+1 entries")
+    n = extend_plan_items(bs, max_seqlen_q)
+    if out is None:
+        out = torch.empty(n, dtype=torch.int32, device=prefix_lens.device)
+    else:
+        _dev_i32(out, "out")
+        _need(out.numel() == n, f"plan needs {n} entries")
+    _check(_lib.msgl_extend_plan(cu_seqlens_q.data_ptr(), prefix_lens.data_ptr(), bs, int(max_seqlen_q), out.data_ptr(), _stream()))
     return out
 
 

@@ -187,6 +187,25 @@ def prepare_decode_ref(req_pool_indices, seq_lens, last_slots, free_pages, free_
     return positions, out_loc, free_head
 
 
+def extend_plan_ref(cu_seqlens_q, prefix_lens, max_seqlen_q: int, q_tile: int = 128, k_tile: int = 64):
+    """Work items of an extend launch with their cost, for checking the device-built launch order.  No counterpart
+    in the reference (its backends leave block scheduling to their attention library); the cost of item
+    b * tiles + qt is the number of `k_tile`-key tiles visible to query rows [q_tile * qt, q_tile * (qt + 1)) of
+    request b under the reference's mask (torch_attn_backend.py:74-101: row i sees positions [0, prefix + i]).
+    Returns (items, key_tiles) for the items that hold at least one query row."""
+    tiles = -(-int(max_seqlen_q) // q_tile)
+    items, cost = [], []
+    for b in range(len(prefix_lens)):
+        n, pre = int(cu_seqlens_q[b + 1]) - int(cu_seqlens_q[b]), int(prefix_lens[b])
+        for qt in range(tiles):
+            if qt * q_tile >= n:
+                break
+            visible = min(pre + n, pre + (qt + 1) * q_tile)
+            items.append(b * tiles + qt)
+            cost.append(-(-visible // k_tile))
+    return items, cost
+
+
 def paged_attention_fp64(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, tok: torch.Tensor, scale: float,
                          q_positions: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Exact softmax(q K^T) V in float64 for ONE request: q [Sq, Hq, D], tok = its slot list [S].

@@ -196,12 +196,14 @@ def build_extend_case(Hq, Hkv, page_size, prefix_lens, input_lens, seed):
                 prefix=torch.tensor(prefix_lens, dtype=torch.int32), inp=torch.tensor(input_lens, dtype=torch.int32))
 
 
-def run_extend(case, page_size):
+def run_extend(case, page_size, max_seqlen_k=0, planned=False):
     ops = _ops()
     kvd = case["kv"].to(DEV)
     cu = torch.nn.functional.pad(torch.cumsum(case["inp"], 0, dtype=torch.int32), (1, 0)).to(DEV)
+    plan = ops.extend_plan(cu, case["prefix"].to(DEV), int(case["inp"].max())) if planned else None
     out = ops.paged_extend(case["q"].to(DEV), kvd[:, 0], kvd[:, 1], case["r2t"].to(DEV), case["req_idx"].to(DEV), cu,
-                           case["prefix"].to(DEV), int(case["inp"].max()), 128 ** -0.5, page_size)
+                           case["prefix"].to(DEV), int(case["inp"].max()), 128 ** -0.5, page_size, max_seqlen_k=max_seqlen_k,
+                           plan=plan)
     torch.cuda.synchronize()
     return out.cpu()
 
@@ -249,6 +251,56 @@ def test_extend_few_queries_on_long_unaligned_prefixes(heads_per_group, monkeypa
     monkeypatch.setenv("MSGL_EXTEND_NH", str(heads_per_group))
     case = build_extend_case(8, 2, 1, [4097, 33, 63, 64, 0], [1, 5, 2, 1, 1], seed=41)
     check_extend(case, run_extend(case, 1))
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(16, 8), (32, 8), (8, 1), (4, 4)])
+@pytest.mark.parametrize("page_size", [1, 16])
+def test_extend_short_requests_two_slot_kernel(Hq, Hkv, page_size):
+    """With the longest request announced (max_seqlen_k) and short, the library takes the kernel with a two-slot
+    ring and one head per work group; 0 (unknown) takes the three-slot one.  Same oracle, same bar, and the two
+    kernels agree to the last bit (same arithmetic in the same order, only the staging differs)."""
+    ps = page_size
+    prefix = [0, 0, 2 * ps, 0, 16 * ps if ps > 1 else 64, 0, 448]
+    inputs = [1, 31, 33, 128, 200, 300, 320]
+    case = build_extend_case(Hq, Hkv, ps, prefix, inputs, seed=5 + Hq + ps)
+    kmax = max(p + n for p, n in zip(prefix, inputs))
+    assert kmax <= 768
+    out = run_extend(case, ps, max_seqlen_k=kmax)
+    check_extend(case, out)
+    assert torch.equal(out, run_extend(case, ps, max_seqlen_k=0))
+
+
+def test_extend_plan_orders_items_longest_first():
+    """The device-built launch order against a numpy restatement: same items, non-increasing key-tile counts,
+    -1 tail; ragged batch with empty-prefix, long-prefix and single-token requests, and a batch wider than the
+    1024 threads of the planning kernel."""
+    ops = _ops()
+    for prefix, inp in [([0, 1024, 0, 4096, 0, 0, 2048, 0], [100, 300, 2000, 50, 700, 4000, 128, 1500]),
+                        ([0], [1]), ([70000, 3], [129, 128]),
+                        (list(range(0, 3000, 2)), [1 + (7 * i) % 300 for i in range(1500)])]:
+        cu = torch.nn.functional.pad(torch.cumsum(torch.tensor(inp, dtype=torch.int32), 0, dtype=torch.int32), (1, 0))
+        pre = torch.tensor(prefix, dtype=torch.int32)
+        plan = ops.extend_plan(cu.to(DEV), pre.to(DEV), max(inp)).cpu()
+        items, tiles = orc.extend_plan_ref(cu, pre, max(inp))
+        n_real = len(items)
+        assert plan.numel() == len(prefix) * (-(-max(inp) // 128))
+        assert (plan[n_real:] == -1).all()
+        got = plan[:n_real].tolist()
+        assert sorted(got) == sorted(items)
+        cost = dict(zip(items, tiles))
+        got_cost = [min(cost[i], 2047) for i in got]
+        assert got_cost == sorted(got_cost, reverse=True)
+
+
+@pytest.mark.parametrize("forced_ring", [None, "2"])
+def test_extend_planned_launch_is_bit_identical(forced_ring, monkeypatch):
+    """The plan only permutes work groups: same bits with and without it, on a ragged batch with shared shapes."""
+    if forced_ring:
+        monkeypatch.setenv("MSGL_EXTEND_ST", forced_ring)
+    case = build_extend_case(16, 8, 16, [0, 1024, 0, 2048, 0, 16], [100, 300, 900, 50, 1, 128], seed=51)
+    base = run_extend(case, 16)
+    check_extend(case, base)
+    assert torch.equal(base, run_extend(case, 16, planned=True))
 
 
 def test_extend_full_size_rows_match_decode_and_fp64():

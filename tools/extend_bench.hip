@@ -99,7 +99,8 @@ int main(int argc, char** argv) {
     CK(hipStreamCreate(&st));
     auto step = [&]() {
         const int rc = msgl_paged_extend(q, (int64_t)hq * D, kv, kv + row, cache_stride, d_r2t, max_ctx, d_idx, d_cu, d_pre, out,
-                                         (int64_t)hq * D, bs, sq, hq, hkv, D, ps, 0.08838834764831845f, st);
+                                         (int64_t)hq * D, bs, sq, /*max_seqlen_k=*/0, /*plan=*/nullptr, hq, hkv, D, ps,
+                                         0.08838834764831845f, st);
         if (rc != 0) {
             fprintf(stderr, "msgl_paged_extend: %d %s\n", rc, msgl_last_error());
             exit(1);
