@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MSGL_HIP_LIB", os.path.join(_HERE, "libmsgl_hip.so"))
 
 ABI_VERSION = 5
 
-# name -> (restype, argtypes); mirrors include/msgl_hip.h one to one
+# name -> (restype, argtypes); mirrors include/msgl_hip.h and include/msgl_comm.h one to one
 SIGNATURES = {
     "msgl_abi_version": (c_int, []),
     "msgl_last_error": (c_char_p, []),
@@ -55,6 +55,13 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
          c_void_p, c_void_p, c_int, c_int, c_void_p],
     ),
+    # include/msgl_comm.h
+    "msgl_ar_create": (c_int, [c_int, c_int, c_size_t, ctypes.POINTER(c_void_p)]),
+    "msgl_ar_export": (c_int, [c_void_p, c_void_p]),
+    "msgl_ar_open": (c_int, [c_void_p, c_void_p]),
+    "msgl_ar_allreduce_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_size_t, c_void_p]),
+    "msgl_ar_check": (c_int, [c_void_p]),
+    "msgl_ar_destroy": (c_int, [c_void_p]),
 }
 
 

@@ -21,6 +21,8 @@ import torch.distributed as dist
 import torch.nn.functional as F
 from torch import nn
 
+from ..comm import tp_all_reduce
+
 
 @dataclasses.dataclass
 class Qwen3Config:
@@ -99,7 +101,7 @@ class Qwen3Attention(nn.Module):
             o = self.attn(q, k, v, batch)
         out = F.linear(o, self.o_proj)
         if _tp()[1] > 1:
-            dist.all_reduce(out)
+            tp_all_reduce(out)
         return out
 
 
@@ -117,7 +119,7 @@ class Qwen3MLP(nn.Module):
         x = self.act_fn(F.linear(x, self.gate_up_proj))
         x = F.linear(x, self.down_proj)
         if _tp()[1] > 1:
-            dist.all_reduce(x)
+            tp_all_reduce(x)
         return x
 
 
@@ -162,7 +164,7 @@ class Qwen3ForCausalLM(nn.Module):
         mask = (input_ids >= self.vocab_start) & (input_ids < self.vocab_start + self.vocab_per_rank)
         y = F.embedding(mask * (input_ids - self.vocab_start), self.embed_tokens)
         y = mask.unsqueeze(1) * y
-        dist.all_reduce(y)
+        tp_all_reduce(y)
         return y
 
     def forward_hidden(self, input_ids: torch.Tensor, positions: torch.Tensor, batch) -> torch.Tensor:

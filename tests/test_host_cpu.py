@@ -14,12 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from mini_sglang_amd import _capi
 
-    header = open(os.path.join(ROOT, "include", "msgl_hip.h")).read()
-    declared = set(re.findall(r"\b(msgl_[a-z0-9_]+)\s*\(", header))
+    header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("msgl_hip.h", "msgl_comm.h"))
+    declared = set(re.findall(r"\b(msgl_[a-z0-9_]+)\s*\(", header)) - {"msgl_ar"}
     assert declared, "no declarations found"
     lib = ctypes.CDLL(_capi.LIB_PATH)
     for name in sorted(declared):
-        assert hasattr(lib, name), f"{name} declared in include/msgl_hip.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/msgl_hip.h or msgl_comm.h but not exported"
     assert declared == set(_capi.SIGNATURES), "ctypes binding and header disagree"
     assert _capi.lib.msgl_abi_version() == _capi.ABI_VERSION
     assert _capi.lib.msgl_paged_decode_workspace_bytes(2, 4, 128, 3) == 2 * 3 * 4 * 130 * 4

@@ -1,0 +1,40 @@
+"""Direct-read all-reduce (include/msgl_comm.h) with 2, 4 and 8 ranks, one process each, against the fp32
+rank-order sum it is specified to return (bit-exact), in both forms, back to back and under graph replay."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_allreduce_matches_rank_order_fp32_sum(world):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "ar_worker.py")], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs, failed = [], False
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=150)
+        except subprocess.TimeoutExpired:
+            failed = True
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()  # exactly the processes started above
+            out, _ = p.communicate()
+            out += "\n[timed out]"
+        outs.append(out)
+    report = "\n".join(f"--- rank {r} (exit {p.returncode})\n{o[-2000:]}" for r, (p, o) in enumerate(zip(procs, outs)))
+    print(report)
+    assert not failed and all(p.returncode == 0 for p in procs), report
