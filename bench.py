@@ -227,8 +227,26 @@ def main():
         result["other_configs"] = other_decode_configs(args, world, rank)
     if not args.no_extend:
         result["extend"] = extend_attention(args, world, rank)
+    xgmi_ok = False
+    if world > 1 and not args.no_e2e:
+        result["tp_allreduce"] = tp_allreduce_trial(world, rank, barrier)
+        xgmi_ok = bool(result["tp_allreduce"].get("validated"))
     if not args.no_e2e:
         result["decode_e2e"] = decode_e2e(args, world, rank, barrier)
+        if xgmi_ok:  # the same steps with the o_proj / down_proj / embedding all-reduces on direct peer reads
+            from mini_sglang_amd import comm
+
+            try:
+                import gc
+
+                gc.collect()
+                torch.cuda.empty_cache()
+                comm.enable_xgmi_allreduce()
+                again = decode_e2e(args, world, rank, barrier)
+                result["decode_e2e"]["xgmi_allreduce"] = {k: again[k] for k in again
+                                                          if k.startswith(("tok_per_s", "ms_per_step", "error", "ctx", "hip_graph"))}
+            finally:
+                comm.disable_xgmi_allreduce()
     watchdog.cancel()
     emit()
     if world > 1:
@@ -408,6 +426,72 @@ def decode_e2e(args, world, rank, barrier):
         return info
     except Exception as e:  # the headline number above must survive a failure here
         return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def tp_allreduce_trial(world, rank, barrier):
+    """The direct-read all-reduce (include/msgl_comm.h) next to RCCL's on the sizes a decode step reduces
+    ([bs, 4096] bf16 for bs 1 .. 256).  It is only used for the second decode_e2e measurement when every rank's
+    result equals the fp32 rank-order sum of the gathered inputs bit for bit and no kernel timed out."""
+    import torch.distributed as dist
+
+    from mini_sglang_amd.comm import XgmiAllReduce
+
+    info = {"validated": False}
+    try:
+        comm = XgmiAllReduce(max_bytes=8 << 20)  # raises on every rank or on none
+        dev = torch.device("cuda", torch.cuda.current_device())
+        cases = []
+        for n in (4096, 64 * 4096, 256 * 4096):  # torch collectives first ...
+            g = torch.Generator(device=dev).manual_seed(17 * n + rank)
+            x = torch.randn(n, device=dev, generator=g).bfloat16()
+            parts = [torch.empty_like(x) for _ in range(world)]
+            dist.all_gather(parts, x)
+            want = torch.zeros(n, dtype=torch.float32, device=dev)
+            for p in parts:
+                want += p.float()
+            cases.append((x, want.bfloat16()))
+        ok = True
+        try:  # ... then only the kernels under test, so that a local failure cannot desynchronise the ranks
+            for x, want in cases:
+                got = comm.all_reduce(x.clone())
+                comm.check()
+                ok = ok and torch.equal(got, want)
+        except Exception as e:  # noqa: BLE001
+            ok = False
+            info["error"] = f"{type(e).__name__}: {e}"[:300]
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        info["validated"] = bool(int(flag[0]))
+        if not info["validated"]:
+            return info
+
+        def timed(fn, x, iters=100):
+            for _ in range(10):
+                fn(x)
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn(x)
+            e1.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) / iters * 1e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return round(float(t[0]), 2)
+
+        sizes = {}
+        for bs in (1, 16, 64, 256):
+            x = torch.zeros(bs * 4096, dtype=torch.bfloat16, device=dev)
+            sizes[f"{bs}x4096"] = {"xgmi_us": timed(comm.all_reduce, x)}
+            if dist.get_backend() == "nccl":  # (the CPU-side gloo group of the tests has nothing to compare with)
+                sizes[f"{bs}x4096"]["rccl_us"] = timed(dist.all_reduce, x)
+        comm.check()
+        info["sizes"] = sizes
+        comm.close()
+    except Exception as e:
+        info["validated"] = False
+        info["error"] = f"{type(e).__name__}: {e}"[:300]
+    return info
 
 
 def cpu_baseline(pool, q, r2t, S, ps, Hq, Hkv, D, scale, budget_s):

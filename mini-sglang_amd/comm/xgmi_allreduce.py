@@ -38,14 +38,34 @@ class XgmiAllReduce:
         self.max_bytes = -(-int(max_bytes) // unit) * unit
         self.one_shot_bytes = int(one_shot_bytes)
         self._h = ctypes.c_void_p()
+        # Every rank takes part in both exchanges below whatever happened locally, so a failure on one rank
+        # surfaces as the same exception on all of them instead of a hang in the next collective.
+        payload, problem = b"", None
         with torch.cuda.device(self.device):
-            _capi.check(_lib.msgl_ar_create(self.rank, self.world, self.max_bytes, ctypes.byref(self._h)))
-            mine = ctypes.create_string_buffer(EXPORT_BYTES)
-            _capi.check(_lib.msgl_ar_export(self._h, mine))
+            try:
+                _capi.check(_lib.msgl_ar_create(self.rank, self.world, self.max_bytes, ctypes.byref(self._h)))
+                mine = ctypes.create_string_buffer(EXPORT_BYTES)
+                _capi.check(_lib.msgl_ar_export(self._h, mine))
+                payload = mine.raw
+            except Exception as e:  # noqa: BLE001 - reported below, on every rank
+                problem = f"rank {self.rank}: {e}"
             everyone = [None] * self.world
-            dist.all_gather_object(everyone, mine.raw, group=group)  # also: every rank has created its flags
-            _capi.check(_lib.msgl_ar_open(self._h, b"".join(everyone)))
-        dist.barrier(group=group)
+            dist.all_gather_object(everyone, (payload, problem), group=group)  # also: every rank has zeroed its flags
+            if all(p == "" or p is None for _, p in everyone) and all(len(h) == EXPORT_BYTES for h, _ in everyone):
+                try:
+                    _capi.check(_lib.msgl_ar_open(self._h, b"".join(h for h, _ in everyone)))
+                except Exception as e:  # noqa: BLE001
+                    problem = f"rank {self.rank}: {e}"
+            else:
+                problem = problem or "a peer could not set up its buffers"
+            verdicts = [None] * self.world
+            dist.all_gather_object(verdicts, problem, group=group)
+        failures = [v for v in verdicts if v]
+        if failures:
+            if self._h:
+                _lib.msgl_ar_destroy(self._h)
+                self._h = ctypes.c_void_p()
+            raise RuntimeError("XgmiAllReduce setup failed: " + "; ".join(failures))
 
     def fits(self, t: torch.Tensor) -> bool:
         return (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.numel() % 8 == 0

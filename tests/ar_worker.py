@@ -25,6 +25,9 @@ def expected_sum(numel, seed, world):
 
 
 def main():
+    import faulthandler
+
+    faulthandler.dump_traceback_later(60, exit=True)  # a stuck rank says where, then leaves
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -32,6 +35,13 @@ def main():
     torch.cuda.set_device(dev)
     from mini_sglang_amd.comm import XgmiAllReduce
 
+    if len(sys.argv) > 1 and sys.argv[1] == "bench-trial":  # the validated trial bench.py runs under TP
+        import bench
+
+        info = bench.tp_allreduce_trial(world, rank, dist.barrier)
+        print(f"rank {rank}/{world}: {info}", flush=True)
+        dist.destroy_process_group()
+        sys.exit(0 if info.get("validated") and "sizes" in info else 1)
     comm = XgmiAllReduce(max_bytes=4 << 20)
     sizes = [8, 512, 3 * 4096 + 8, 131072 + 8, 1 << 20]
     bad = []

@@ -17,11 +17,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_allreduce_matches_rank_order_fp32_sum(world):
+def _run_ranks(world, *args):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
                HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
-    procs = [subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "ar_worker.py")], env=dict(env, RANK=str(r)),
+    procs = [subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "ar_worker.py"), *args], env=dict(env, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs, failed = [], False
     for p in procs:
@@ -38,3 +37,13 @@ def test_allreduce_matches_rank_order_fp32_sum(world):
     report = "\n".join(f"--- rank {r} (exit {p.returncode})\n{o[-2000:]}" for r, (p, o) in enumerate(zip(procs, outs)))
     print(report)
     assert not failed and all(p.returncode == 0 for p in procs), report
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_allreduce_matches_rank_order_fp32_sum(world):
+    _run_ranks(world)
+
+
+def test_bench_trial_validates_and_times():
+    """The trial bench.py runs before it trusts the direct-read all-reduce for the decode measurement."""
+    _run_ranks(2, "bench-trial")
