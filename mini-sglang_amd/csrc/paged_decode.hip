@@ -142,33 +142,53 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
         tok = min(tok, t1 - 1);
         return r2t_row[tok];
     };
-    // element offsets of the rows this lane loads for a tile whose table entry is idx: K tokens 8t + o,
-    // V tokens 8t + 2j + b (instruction i = 2t + b)
-    auto tile_offsets = [&](int idx, int64_t (&koff)[2], int64_t (&voff)[4]) {
+    // Row addresses of the tile whose table entry is idx: K tokens 8t + o, V tokens 8t + 2j + b (instruction
+    // i = 2t + b).  PAGED16: the 16 slots are consecutive, so an address is a wave-uniform base (scalar
+    // arithmetic on idx) plus a byte offset that never changes for the lane, and the tile costs next to no
+    // vector address arithmetic -- used where the vector pipe is the limit (G = 8; with fewer heads the kernel
+    // waits on memory and measured the same either way).  Otherwise every lane multiplies its own slot.
+    constexpr bool UNIFORM_BASE = PAGED16 && G >= 8;
+    uint32_t klane[2], vlane[4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int tk = 8 * t + o;
-            const int slot = PAGED16 ? idx + tk : __shfl(idx, tk & 15, 16);
-            koff[t] = (int64_t)slot * p.cache_stride;
-        }
+    for (int t = 0; t < 2; ++t) klane[t] = (uint32_t)(((8 * t + o) * p.cache_stride + s8 * 8) * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int tv = 8 * (i >> 1) + 2 * j + (i & 1);
-            const int slot = PAGED16 ? idx + tv : __shfl(idx, tv, 16);
-            voff[i] = (int64_t)slot * p.cache_stride;
+    for (int i = 0; i < 4; ++i) vlane[i] = (uint32_t)(((8 * (i >> 1) + 2 * j + (i & 1)) * p.cache_stride + c * 8) * 2);
+    auto tile_rows = [&](int idx, const uint16_t* (&kp)[2], const uint16_t* (&vp)[4]) {
+        if constexpr (UNIFORM_BASE) {
+            const int64_t first = (int64_t)__builtin_amdgcn_readfirstlane(idx) * p.cache_stride + h * kD;
+            const char* kt = reinterpret_cast<const char*>(p.kc + first);
+            const char* vt = reinterpret_cast<const char*>(p.vc + first);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) kp[t] = reinterpret_cast<const uint16_t*>(kt + klane[t]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vp[i] = reinterpret_cast<const uint16_t*>(vt + vlane[i]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int tk = 8 * t + o;
+                kp[t] = kbase + (int64_t)(PAGED16 ? idx + tk : __shfl(idx, tk & 15, 16)) * p.cache_stride;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int tv = 8 * (i >> 1) + 2 * j + (i & 1);
+                vp[i] = vbase + (int64_t)(PAGED16 ? idx + tv : __shfl(idx, tv, 16)) * p.cache_stride;
+            }
         }
     };
 
     uint4 kb[DEPTH][4], vb[DEPTH][4];  // kb[.][2t + k]: half row k of token 8t + o; vb[.][i]: row of token 8(i>>1) + 2j + (i&1)
     // One tile: scores from kb[st]; refill kb[st] with own tile n + DEPTH; softmax; P.V from vb[st];
     // refill vb[st].  idx_refill is the table entry of tile n + DEPTH (REFILL only).
-    auto tile_step = [&](auto st_tag, auto refill_tag, int n, int idx_refill) {
+    // FULL: every token of the tile lies inside the split (all tiles but a wave's last one), no masking.
+    auto tile_step = [&](auto st_tag, auto refill_tag, auto full_tag, int n, int idx_refill) {
         constexpr int st = decltype(st_tag)::value;
         constexpr int RF = decltype(refill_tag)::value;  // 0: no refill, 1: refill with cached loads, 2: non-temporal
         constexpr bool REFILL = RF != 0;
         constexpr bool NT = RF == 2;
-        int64_t koff[2], voff[4];
-        if (REFILL) tile_offsets(idx_refill, koff, voff);
+        constexpr bool FULL = decltype(full_tag)::value && G >= 8;  // (as above: only pays where the vector pipe is the limit)
+        const uint16_t* kp[2];
+        const uint16_t* vp[4];
+        if (REFILL) tile_rows(idx_refill, kp, vp);
 
         const int tok0 = t0 + (sub + n * WPH) * kTile + o;  // this lane's K token of half t is tok0 + 8t
         // query heads are taken GS at a time (scores -> softmax -> P.V per group) so that only a few
@@ -191,7 +211,7 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
                     d = dot2_bf16(qv[g][1].z, kb[st][2 * t + 1].z, d);
                     d = dot2_bf16(qv[g][1].w, kb[st][2 * t + 1].w, d);
                     d = octet_sum(d);
-                    s[gg][t] = (tok0 + 8 * t < t1) ? d * p.scale_log2e : -INFINITY;
+                    s[gg][t] = (FULL || tok0 + 8 * t < t1) ? d * p.scale_log2e : -INFINITY;
                 }
             }
             if (REFILL && g0 + GS >= G) {
@@ -200,7 +220,7 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) kb[st][2 * t + k] = ld16_kv<NT>(kbase + koff[t] + k * 64);
+                    for (int k = 0; k < 2; ++k) kb[st][2 * t + k] = ld16_kv<NT>(kp[t] + k * 64);
                 __builtin_amdgcn_sched_barrier(0);
             }
             float pr[GS][2];
@@ -243,10 +263,12 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
         if (REFILL) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vb[st][i] = ld16_kv<NT>(vbase + voff[i]);
+            for (int i = 0; i < 4; ++i) vb[st][i] = ld16_kv<NT>(vp[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    using FULL_ = std::true_type;
+    using EDGE_ = std::false_type;
     using F_ = std::integral_constant<int, 0>;   // no refill
     using T_ = std::integral_constant<int, 1>;   // refill, cached loads
     using NT_ = std::integral_constant<int, 2>;  // refill, non-temporal loads
@@ -256,14 +278,15 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
     {
 #pragma unroll
         for (int st = 0; st < DEPTH; ++st) {
-            int64_t koff[2], voff[4];
-            tile_offsets(load_index(st), koff, voff);
+            const uint16_t* kp[2];
+            const uint16_t* vp[4];
+            tile_rows(load_index(st), kp, vp);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int k = 0; k < 2; ++k) kb[st][2 * t + k] = ld16_kv<false>(kbase + koff[t] + k * 64);
+                for (int k = 0; k < 2; ++k) kb[st][2 * t + k] = ld16_kv<false>(kp[t] + k * 64);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vb[st][i] = ld16_kv<false>(vbase + voff[i]);
+            for (int i = 0; i < 4; ++i) vb[st][i] = ld16_kv<false>(vp[i]);
         }
         idx_next = load_index(DEPTH);
     }
@@ -285,24 +308,24 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
         if constexpr (DEPTH >= 1) {
             const int idx_r = idx_next;
             idx_next = load_index(n0 + 0 + DEPTH + 1);
-            tile_step(std::integral_constant<int, 0>{}, T_{}, n0 + 0, idx_r);
+            tile_step(std::integral_constant<int, 0>{}, T_{}, FULL_{}, n0 + 0, idx_r);
         }
         if constexpr (DEPTH >= 2) {
             const int idx_r = idx_next;
             idx_next = load_index(n0 + 1 + DEPTH + 1);
-            tile_step(std::integral_constant<int, 1>{}, T_{}, n0 + 1, idx_r);
+            tile_step(std::integral_constant<int, 1>{}, T_{}, FULL_{}, n0 + 1, idx_r);
         }
     }
     for (; n0 + 2 * DEPTH <= my_tiles; n0 += DEPTH) {
         if constexpr (DEPTH >= 1) {
             const int idx_r = idx_next;
             idx_next = load_index(n0 + 0 + DEPTH + 1);
-            tile_step(std::integral_constant<int, 0>{}, NT_{}, n0 + 0, idx_r);
+            tile_step(std::integral_constant<int, 0>{}, NT_{}, FULL_{}, n0 + 0, idx_r);
         }
         if constexpr (DEPTH >= 2) {
             const int idx_r = idx_next;
             idx_next = load_index(n0 + 1 + DEPTH + 1);
-            tile_step(std::integral_constant<int, 1>{}, NT_{}, n0 + 1, idx_r);
+            tile_step(std::integral_constant<int, 1>{}, NT_{}, FULL_{}, n0 + 1, idx_r);
         }
     }
     // tail: at most 2*DEPTH - 1 tiles; refill only where the target exists
@@ -311,9 +334,9 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
             if (n0 + 0 + DEPTH < my_tiles) {
                 const int idx_r = idx_next;
                 idx_next = load_index(n0 + 0 + DEPTH + 1);
-                tile_step(std::integral_constant<int, 0>{}, T_{}, n0 + 0, idx_r);
+                tile_step(std::integral_constant<int, 0>{}, T_{}, EDGE_{}, n0 + 0, idx_r);
             } else {
-                tile_step(std::integral_constant<int, 0>{}, F_{}, n0 + 0, 0);
+                tile_step(std::integral_constant<int, 0>{}, F_{}, EDGE_{}, n0 + 0, 0);
             }
         }
     }
@@ -322,12 +345,12 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
             if (n0 + 1 + DEPTH < my_tiles) {
                 const int idx_r = idx_next;
                 idx_next = load_index(n0 + 1 + DEPTH + 1);
-                tile_step(std::integral_constant<int, 1>{}, T_{}, n0 + 1, idx_r);
+                tile_step(std::integral_constant<int, 1>{}, T_{}, EDGE_{}, n0 + 1, idx_r);
             } else {
-                tile_step(std::integral_constant<int, 1>{}, F_{}, n0 + 1, 0);
+                tile_step(std::integral_constant<int, 1>{}, F_{}, EDGE_{}, n0 + 1, 0);
             }
         }
-        if (n0 + 2 < my_tiles) tile_step(std::integral_constant<int, 0>{}, F_{}, n0 + 2, 0);
+        if (n0 + 2 < my_tiles) tile_step(std::integral_constant<int, 0>{}, F_{}, EDGE_{}, n0 + 2, 0);
     }
 
     // merge the 4 DPP rows of the wave (tokens were dealt round-robin to rows)
