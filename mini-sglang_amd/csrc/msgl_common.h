@@ -46,6 +46,14 @@ __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
 }
 
+// a.lo*b.lo + a.hi*b.hi: the three-operand encoding with a literal zero addend, for the first step of a chain
+// (the compiler's choice, the accumulate-in-place encoding, would need its destination zeroed first).
+__device__ __forceinline__ float dot2_bf16_first(uint32_t a, uint32_t b) {
+    float r;
+    asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // DPP lane movement inside a row of 16 lanes; fuses into the consuming VALU op.
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float x) {

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
 #pragma unroll
                 for (int gg = 0; gg < GS; ++gg) {
                     const int g = g0 + gg;
-                    float d = dot2_bf16(qv[g][0].x, kb[st][2 * t].x, 0.f);
+                    float d = dot2_bf16_first(qv[g][0].x, kb[st][2 * t].x);
                     d = dot2_bf16(qv[g][0].y, kb[st][2 * t].y, d);
                     d = dot2_bf16(qv[g][0].z, kb[st][2 * t].z, d);
                     d = dot2_bf16(qv[g][0].w, kb[st][2 * t].w, d);
@@ -233,9 +233,7 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
                 const float alpha = fast_exp2(m[g] - mn);
                 pr[gg][0] = fast_exp2(s[gg][0] - mn);
                 pr[gg][1] = fast_exp2(s[gg][1] - mn);
-                float ps = pr[gg][0] + pr[gg][1];
-                ps += dpp_f32<DPP_ROW_ROR8>(ps);
-                l[g] = l[g] * alpha + ps;
+                l[g] = l[g] * alpha + (pr[gg][0] + pr[gg][1]);  // this octet's tokens only; the two octets meet after the loop
                 m[g] = mn;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[g][e] *= alpha;
@@ -359,7 +357,7 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
         float M = fmaxf(m[g], __shfl_xor(m[g], 16));
         M = fmaxf(M, __shfl_xor(M, 32));
         const float w = fast_exp2(m[g] - M);
-        float lg = l[g] * w;
+        float lg = (l[g] + dpp_f32<DPP_ROW_ROR8>(l[g])) * w;  // both octets of the row, then the four rows
         lg += __shfl_xor(lg, 16);
         lg += __shfl_xor(lg, 32);
         l[g] = lg;
