@@ -279,15 +279,18 @@ def other_decode_configs(args, world, rank):
         r2t, sl = pt.req_to_token.to(dev), pt.seq_lens.to(dev)
         idx = torch.arange(bs, dtype=torch.int32, device=dev)
         ms = splits_for_batch(bs)
-        chunk = ops.pick_split(max(lens), sum(lens), bs, ms, Hkv)
+        # what the backend does per step: ragged batches get the split size of the schedule model and a launch plan
+        ragged = max(lens) * bs > 1.25 * sum(lens)
+        chunk = ops.pick_split_planned(lens, ms, Hkv) if ragged else ops.pick_split(max(lens), sum(lens), bs, ms, Hkv)
         ms = max(1, min(ms, -(-max(lens) // chunk)))
+        plan = ops.decode_plan(sl, ms, chunk) if ragged and ms > 1 else None  # once per step, shared by all layers
         ws = torch.empty(max(16, ops.decode_workspace_bytes(bs, Hq, D, ms)), dtype=torch.uint8, device=dev)
         reuse = torch.tensor([prefix[g] for g in groups], dtype=torch.int32, device=dev) if groups is not None else None
 
         def f(i):
             kv = pools[i % layers]
             ops.paged_decode(q, kv[:, 0], kv[:, 1], r2t, idx, sl, D ** -0.5, ps, out=o, workspace=ws, max_splits=ms,
-                             chunk_tokens=chunk, reuse_lens=reuse)
+                             chunk_tokens=chunk, reuse_lens=reuse, plan=plan)
 
         for i in range(4):
             f(i)
@@ -308,7 +311,8 @@ def other_decode_configs(args, world, rank):
         t = e0.elapsed_time(e1) / steps * 1e-3
         b = 2 * Hkv * D * 2
         out[name] = {"GBps_per_gpu": round(b * sum(lens) / t / 1e9, 1), "unique_GBps_per_gpu": round(b * pt.unique_tokens / t / 1e9, 1),
-                     "ms_per_launch": round(t * 1e3, 4), "frac_of_hbm_peak": round(b * sum(lens) / t / 1e9 / HBM_PEAK_GBPS, 4)}
+                     "ms_per_launch": round(t * 1e3, 4), "frac_of_hbm_peak": round(b * sum(lens) / t / 1e9 / HBM_PEAK_GBPS, 4),
+                     "chunk_tokens": chunk, "planned_launch": plan is not None}
 
     try:
         if world == 1:

@@ -85,6 +85,9 @@ int msgl_store_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stri
  * NULL = no such positions): those are the prefix slots that the radix cache shares between
  * requests (batch_info.py:184-186, 215-219) and are kept cacheable so that the other requests'
  * re-reads hit L2 / the Infinity Cache.  The policy never changes results.
+ * plan: NULL (work groups in split-major order), or the bs * max_splits int32 entries
+ *   msgl_decode_plan wrote for these very seq_lens / max_splits / chunk: the launch order
+ *   for ragged batches.  Scheduling only, never changes results.
  * workspace: >= msgl_paged_decode_workspace_bytes(...) bytes of device memory,
  *   16-byte aligned; contents are scratch.
  * Supported: D == 128; Hq/Hkv in {1, 2, 4, 8}; Hkv in {1, 2, 4, 8}.
@@ -99,8 +102,20 @@ int msgl_paged_decode(const void* q, int64_t q_stride,
                       void* workspace, size_t workspace_bytes,
                       int bs, int Hq, int Hkv, int D, int page_size, float scale,
                       int max_splits, int chunk_tokens, const int32_t* chunk_dev,
-                      int kv_stream, const int32_t* reuse_lens,
+                      int kv_stream, const int32_t* reuse_lens, const int32_t* plan,
                       void* stream);
+
+/* Launch order of msgl_paged_decode's (split, request) work items for a batch of unequal
+ * lengths, built on the device (the lengths are never read back): every full split first, then
+ * each request's partial last split by falling length; item = split * bs + request, unused
+ * entries -1.  One call per decode step serves all layers: it belongs where the FA3 backend
+ * refreshes its per-step metadata (fa3_attn_backend.py:43-82, 189-233) and can be captured in
+ * the step's graph.  plan: int32 [bs * max_splits].  sorted_dev: NULL, or a device word read at
+ * run time: 0 writes the identity order (= the launch without a plan) instead, so that one
+ * captured graph serves uniform and ragged batches. */
+int msgl_decode_plan(const int32_t* seq_lens, int bs, int max_splits,
+                     int chunk_tokens, const int32_t* chunk_dev,
+                     const int32_t* sorted_dev, int32_t* plan, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Paged extend (prefill) attention, variable-length queries, bottom-right causal.

@@ -31,6 +31,7 @@ class HipAttnMetadata:
     chunk_tokens: int = 0
     chunk_dev: Optional[torch.Tensor] = None
     reuse_lens: Optional[torch.Tensor] = None  # per request: leading positions shared with other requests
+    decode_plan: Optional[torch.Tensor] = None  # launch order of the (split, request) items (ragged batches)
     # extend
     cu_seqlens_q: Optional[torch.Tensor] = None
     max_seqlen_q: int = 0
@@ -58,8 +59,11 @@ class HipAttnBackend(AttentionBackend):
         # K/V rows are read once per step: stream them past the caches (non-temporal), keeping only the
         # prefix positions that several requests share cacheable
         self.kv_stream = True
+        self._planned_split = (None, 0)
+        self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count if torch.cuda.is_available() else 256
         self.decode_graph_vars: Optional[dict] = None
         self.decode_graph_metadata: Dict[int, HipAttnMetadata] = {}
+        self.plan_refresh_in_graph = False
 
     # ------------------------------------------------------------------ helpers
     def _workspace_for(self, bs: int, Hq: int, D: int, max_splits: int) -> Optional[torch.Tensor]:
@@ -72,9 +76,19 @@ class HipAttnBackend(AttentionBackend):
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._workspace
 
-    def _decode_split(self, seq_lens_cpu: torch.Tensor, bs: int, max_splits: int) -> int:
+    def _decode_split(self, seq_lens_cpu: torch.Tensor, bs: int, max_splits: int):
+        """(tokens per split, ragged).  A batch whose longest request is well above the average is launched in
+        planned order, with the split size a host-side model of that schedule likes best; the model costs a few
+        milliseconds, so its answer is kept until the batch has grown by 64 tokens per request or changed."""
         kv_heads = int(getattr(self.kv_cache_pool, "head_num", 8))
-        return ops.pick_split(int(seq_lens_cpu.max()), int(seq_lens_cpu.sum()), bs, max_splits, kv_heads)
+        longest, total = int(seq_lens_cpu.max()), int(seq_lens_cpu.sum())
+        if bs == 1 or longest * bs <= 1.25 * total:
+            return ops.pick_split(longest, total, bs, max_splits, kv_heads), False
+        key = (bs, max_splits, total // (64 * bs), longest // 64)
+        if self._planned_split[0] != key:
+            self._planned_split = (key, ops.pick_split_planned(seq_lens_cpu.tolist(), max_splits, kv_heads, self._cus))
+        chunk = max(self._planned_split[1], -(-(-(-longest // max_splits)) // 16) * 16)
+        return chunk, True
 
     # ------------------------------------------------------------------ eager metadata
     def init_forward_metadata(self, batch):
@@ -82,10 +96,12 @@ class HipAttnBackend(AttentionBackend):
         bs = batch.seq_lens.numel()
         if batch.forward_mode.is_decode():
             md.max_splits = splits_for_batch(bs)
-            md.chunk_tokens = self._decode_split(batch.seq_lens_cpu, bs, md.max_splits)
+            md.chunk_tokens, ragged = self._decode_split(batch.seq_lens_cpu, bs, md.max_splits)
             # eager launches know the longest sequence: launch only the splits that can be active
             md.max_splits = max(1, min(md.max_splits, -(-int(batch.seq_lens_cpu.max()) // md.chunk_tokens)))
             md.reuse_lens = getattr(batch, "shared_prefix_lens", None)
+            if ragged and md.max_splits > 1:
+                md.decode_plan = ops.decode_plan(batch.seq_lens, md.max_splits, md.chunk_tokens)
         else:
             md.max_seqlen_q = int(batch.input_seq_lens_max)
             md.max_seqlen_k = int(batch.seq_lens_cpu.max())
@@ -118,15 +134,20 @@ class HipAttnBackend(AttentionBackend):
             batch.req_pool_indices, batch.seq_lens, layer.scale, self.page_size,
             workspace=self._workspace_for(bs, layer.num_heads, layer.head_dim, md.max_splits),
             max_splits=md.max_splits, chunk_tokens=md.chunk_tokens, chunk_dev=md.chunk_dev,
-            kv_stream=self.kv_stream, reuse_lens=md.reuse_lens)
+            kv_stream=self.kv_stream, reuse_lens=md.reuse_lens, plan=md.decode_plan)
         return o.view(bs, layer.num_heads * layer.head_dim)
 
     # ------------------------------------------------------------------ graph hooks
     def init_cuda_graph_state(self, max_bs: int, num_heads: Optional[int] = None, head_dim: int = 128):
         """Static state shared by all captured batch sizes: the 4-byte split-size word and a workspace large
         enough for every (bs, splits_for_batch(bs)) pair (compare fa3_attn_backend.py:154-175)."""
+        most_items = max(bs * splits_for_batch(bs) for bs in range(1, max_bs + 1))
         self.decode_graph_vars = {"chunk": torch.full((1,), 1 << 20, dtype=torch.int32, device=self.device),
-                                  "reuse_lens": torch.zeros(max_bs, dtype=torch.int32, device=self.device)}
+                                  "reuse_lens": torch.zeros(max_bs, dtype=torch.int32, device=self.device),
+                                  # launch order of the captured decode kernels and the word that says whether the
+                                  # next refresh sorts it (ragged batch) or writes the identity (uniform batch)
+                                  "plan": torch.arange(most_items, dtype=torch.int32, device=self.device),
+                                  "plan_sorted": torch.zeros(1, dtype=torch.int32, device=self.device)}
         self.decode_graph_metadata = {}
         if num_heads is None:
             num_heads = getattr(self, "graph_num_heads", None)
@@ -137,8 +158,12 @@ class HipAttnBackend(AttentionBackend):
     def init_forward_metadata_capture_cuda_graph(self, bs: int, forward_mode):
         if forward_mode.is_extend():
             raise NotImplementedError("extend is not captured in a graph")
-        md = HipAttnMetadata(max_splits=splits_for_batch(bs), chunk_dev=self.decode_graph_vars["chunk"],
-                             reuse_lens=self.decode_graph_vars["reuse_lens"][:bs])
+        splits = splits_for_batch(bs)
+        md = HipAttnMetadata(max_splits=splits, chunk_dev=self.decode_graph_vars["chunk"],
+                             reuse_lens=self.decode_graph_vars["reuse_lens"][:bs],
+                             decode_plan=self.decode_graph_vars["plan"][: bs * splits] if splits > 1 else None)
+        if md.decode_plan is not None:  # valid for any lengths until the first refresh
+            md.decode_plan.copy_(torch.arange(bs * splits, dtype=torch.int32, device=self.device))
         self.decode_graph_metadata[bs] = md
         self.forward_metadata = md
 
@@ -150,9 +175,21 @@ class HipAttnBackend(AttentionBackend):
         md = self.decode_graph_metadata[bs]
         if forward_mode.is_decode():
             # padded rows have length 1; they only lower the average, never the maximum
-            chunk = self._decode_split(seq_lens_cpu, bs, md.max_splits)
+            chunk, ragged = self._decode_split(seq_lens_cpu, bs, md.max_splits)
             self.decode_graph_vars["chunk"].fill_(chunk)
+            self.decode_graph_vars["plan_sorted"].fill_(1 if ragged else 0)
+            if not self.plan_refresh_in_graph:
+                self.refresh_decode_plan(bs, seq_lens)
         self.forward_metadata = md
+
+    def refresh_decode_plan(self, bs: int, seq_lens: torch.Tensor) -> None:
+        """Rewrite the static launch order from the lengths now in `seq_lens` (device).  Called by the replay hook;
+        a runner whose captured step changes the lengths itself (device-side batch preparation) sets
+        ``plan_refresh_in_graph`` and calls this inside the step, after the lengths are final."""
+        md = self.decode_graph_metadata[bs]
+        if md.decode_plan is not None:
+            ops.decode_plan(seq_lens[:bs], md.max_splits, chunk_dev=md.chunk_dev, out=md.decode_plan,
+                            sorted_dev=self.decode_graph_vars["plan_sorted"])
 
     def set_graph_reuse_lens(self, shared_prefix_lens: Optional[torch.Tensor]) -> None:
         """Optional, before a replay: per-request shared-prefix lengths for the cache-policy hint (None = none).

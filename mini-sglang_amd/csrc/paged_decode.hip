@@ -23,6 +23,7 @@
 //     sequence lengths; partial results go to a caller-provided workspace and a second
 //     small kernel merges them (requests that fit one split are written directly).
 #include "msgl_common.h"
+#include "plan_sort.h"
 
 #include <type_traits>
 
@@ -49,6 +50,7 @@ struct DecodeParams {
     float* ws_ml;  // [bs, max_splits, Hq, 2]   (running max in log2 units, running sum)
     const int32_t* chunk_dev;
     const int32_t* reuse_lens;  // per request: positions below this may be shared with other requests
+    const int32_t* plan;        // optional launch order of the (split, request) items, see decode_plan_kernel
     int kv_stream;              // 0: every K/V load is cached; 1: loads at or above reuse_lens are non-temporal
     int chunk;
     int bs, Hq, max_splits;
@@ -90,8 +92,13 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
 
     // split-major block order: consecutive blocks (dealt round-robin to the 8 XCDs) are different
     // requests of the same split, so the active blocks cover every XCD whatever the split count is
-    const int split = blockIdx.x / p.bs;
-    const int b = blockIdx.x - split * p.bs;
+    int item = blockIdx.x;
+    if (p.plan) {  // ragged batch: full splits first, the partial tails by falling length after them
+        item = p.plan[blockIdx.x];
+        if (item < 0) return;
+    }
+    const int split = item / p.bs;
+    const int b = item - split * p.bs;
     const int S = p.seq_lens[b];
     const int chunk = split_chunk(p);
     const int nsplit = min((S + chunk - 1) / chunk, p.max_splits);
@@ -415,6 +422,32 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
     }
 }
 
+// Launch order for a ragged decode batch: item = split * bs + request, cost = its number of 16-token tiles.
+// All full splits cost the same and go first; the partial last split of every request follows by falling
+// length, so the work groups still running when the launch drains are the shortest ones.
+// sorted_dev (optional, device): 0 = write the identity order instead (uniform batches keep the split-major launch
+// whose neighbours are different requests of one split); lets a captured graph switch per replay.
+__global__ __launch_bounds__(kPlanThreads) void decode_plan_kernel(DecodeParams p, const int32_t* __restrict__ sorted_dev,
+                                                                   int32_t* __restrict__ plan) {
+    __shared__ int bins[kPlanBins];
+    __shared__ int part[kPlanThreads];
+    if (sorted_dev && *sorted_dev == 0) {
+        for (int i = threadIdx.x; i < p.bs * p.max_splits; i += kPlanThreads) plan[i] = i;
+        return;
+    }
+    const int chunk = split_chunk(p);
+    auto tiles = [&](int i) -> int {
+        const int split = i / p.bs, b = i - split * p.bs;
+        const int S = p.seq_lens[b];
+        const int nsplit = min((S + chunk - 1) / chunk, p.max_splits);
+        if (split >= nsplit) return -1;
+        const int t0 = split * chunk;
+        const int t1 = (split == p.max_splits - 1) ? S : min(S, t0 + chunk);
+        return (t1 - t0 + kTile - 1) / kTile;
+    };
+    plan_sort_descending(p.bs * p.max_splits, tiles, plan, bins, part);
+}
+
 // Merge the split-K partials of one (request, query head).  NW waves take every NW-th split, lane l owns
 // output columns 2l and 2l+1; each thread reads the (max, sum) pairs of its splits once, the split weights
 // are formed in parallel and kept in LDS, so the per-split work is one 8-byte load and two FMAs, four
@@ -584,9 +617,11 @@ extern "C" int msgl_paged_decode(const void* q, int64_t q_stride, const void* k_
                                  const int32_t* req_pool_indices, const int32_t* seq_lens, void* out,
                                  int64_t out_stride, void* workspace, size_t workspace_bytes, int bs, int Hq, int Hkv,
                                  int D, int page_size, float scale, int max_splits, int chunk_tokens,
-                                 const int32_t* chunk_dev, int kv_stream, const int32_t* reuse_lens, void* stream) {
+                                 const int32_t* chunk_dev, int kv_stream, const int32_t* reuse_lens, const int32_t* plan,
+                                 void* stream) {
     if (bs == 0) return MSGL_OK;
     MSGL_REQUIRE(bs > 0, "msgl_paged_decode: bs=%d", bs);
+    MSGL_REQUIRE(cache_stride <= (int64_t)1 << 27, "msgl_paged_decode: cache_stride %lld too large", (long long)cache_stride);
     MSGL_REQUIRE(D == kD, "msgl_paged_decode: head dim %d unsupported (128 only)", D);
     MSGL_REQUIRE(Hkv > 0 && Hq % Hkv == 0, "msgl_paged_decode: Hq=%d not a multiple of Hkv=%d", Hq, Hkv);
     MSGL_REQUIRE(page_size >= 1, "msgl_paged_decode: page_size=%d", page_size);
@@ -625,6 +660,7 @@ extern "C" int msgl_paged_decode(const void* q, int64_t q_stride, const void* k_
     p.ws_ml = p.ws_o ? p.ws_o + (size_t)bs * max_splits * Hq * D : nullptr;
     p.chunk_dev = chunk_dev;
     p.reuse_lens = reuse_lens;
+    p.plan = plan;
     p.kv_stream = kv_stream ? 1 : 0;
     p.chunk = chunk_tokens;
     p.bs = bs;
@@ -640,4 +676,22 @@ extern "C" int msgl_paged_decode(const void* q, int64_t q_stride, const void* k_
     }
     set_error("msgl_paged_decode: Hq/Hkv=%d unsupported (1, 2, 4 or 8)", Hq / Hkv);
     return MSGL_E_INVALID;
+}
+
+extern "C" int msgl_decode_plan(const int32_t* seq_lens, int bs, int max_splits, int chunk_tokens, const int32_t* chunk_dev,
+                                const int32_t* sorted_dev, int32_t* plan, void* stream) {
+    if (bs == 0) return MSGL_OK;
+    MSGL_REQUIRE(bs > 0 && max_splits >= 1 && max_splits <= 4096, "msgl_decode_plan: bs=%d max_splits=%d", bs, max_splits);
+    MSGL_REQUIRE((int64_t)bs * max_splits <= 0x7fffffff, "msgl_decode_plan: too many items");
+    MSGL_REQUIRE(chunk_dev != nullptr || (chunk_tokens > 0 && chunk_tokens % kTile == 0),
+                 "msgl_decode_plan: chunk_tokens=%d must be a positive multiple of %d", chunk_tokens, kTile);
+    MSGL_REQUIRE(seq_lens && plan, "msgl_decode_plan: null pointer argument");
+    DecodeParams p = {};
+    p.seq_lens = seq_lens;
+    p.chunk_dev = chunk_dev;
+    p.chunk = chunk_tokens;
+    p.bs = bs;
+    p.max_splits = max_splits;
+    hipLaunchKernelGGL(decode_plan_kernel, dim3(1), dim3(kPlanThreads), 0, static_cast<hipStream_t>(stream), p, sorted_dev, plan);
+    return check_launch("decode_plan_kernel");
 }

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "msgl_common.h"
+#include "plan_sort.h"
 
 namespace msgl {
 
@@ -484,49 +485,19 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
 // hardware's in-order dispatch becomes longest-processing-time-first scheduling; items past a request's
 // length are dropped and the rest of `plan` is filled with -1.  Items of equal cost land in arbitrary order
 // (LDS atomics); the attention output does not depend on the order.
-constexpr int kPlanBins = 2048;
-__global__ __launch_bounds__(1024) void extend_plan_kernel(const int32_t* __restrict__ cu_q, const int32_t* __restrict__ prefix, int bs,
-                                                           int tiles_per_req, int32_t* __restrict__ plan) {
-    __shared__ int bins[kPlanBins];   // bin r holds the items with kPlanBins - 1 - r key tiles (clamped): ascending r = descending cost
-    __shared__ int part[1024];
-    const int tid = threadIdx.x;
-    const int n = bs * tiles_per_req;
-    for (int i = tid; i < kPlanBins; i += 1024) bins[i] = 0;
-    __syncthreads();
-    auto bin_of = [&](int i) -> int {
+__global__ __launch_bounds__(kPlanThreads) void extend_plan_kernel(const int32_t* __restrict__ cu_q, const int32_t* __restrict__ prefix, int bs,
+                                                                   int tiles_per_req, int32_t* __restrict__ plan) {
+    __shared__ int bins[kPlanBins];
+    __shared__ int part[kPlanThreads];
+    auto key_tiles = [&](int i) -> int {
         const int b = i / tiles_per_req, qt = i - b * tiles_per_req;
         const int Sq = cu_q[b + 1] - cu_q[b];
         if (qt * kBM >= Sq) return -1;
         const int pre = prefix[b];
         const int kv_len = min(pre + Sq, pre + qt * kBM + kBM);
-        return kPlanBins - 1 - min((kv_len + kBN - 1) / kBN, kPlanBins - 1);
+        return (kv_len + kBN - 1) / kBN;
     };
-    for (int i = tid; i < n; i += 1024) {
-        const int r = bin_of(i);
-        if (r >= 0) atomicAdd(&bins[r], 1);
-    }
-    __syncthreads();
-    // exclusive scan of the bins: two per thread, then Hillis-Steele over the 1024 partial sums
-    const int c0 = bins[2 * tid], c1 = bins[2 * tid + 1];
-    part[tid] = c0 + c1;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const int add = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += add;
-        __syncthreads();
-    }
-    const int before = part[tid] - (c0 + c1);
-    const int total = part[1023];
-    __syncthreads();
-    bins[2 * tid] = before;
-    bins[2 * tid + 1] = before + c0;
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const int r = bin_of(i);
-        if (r >= 0) plan[atomicAdd(&bins[r], 1)] = i;
-    }
-    for (int i = total + tid; i < n; i += 1024) plan[i] = -1;
+    plan_sort_descending(bs * tiles_per_req, key_tiles, plan, bins, part);
 }
 
 template <int NH, int ST>
@@ -619,7 +590,7 @@ extern "C" int msgl_extend_plan(const int32_t* cu_seqlens_q, const int32_t* pref
     MSGL_REQUIRE(cu_seqlens_q && prefix_lens && plan, "msgl_extend_plan: null pointer argument");
     const int64_t n = msgl_extend_plan_items(bs, max_seqlen_q);
     MSGL_REQUIRE(n <= 0x7fffffff, "msgl_extend_plan: %lld items", (long long)n);
-    hipLaunchKernelGGL(extend_plan_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), cu_seqlens_q, prefix_lens, bs,
+    hipLaunchKernelGGL(extend_plan_kernel, dim3(1), dim3(kPlanThreads), 0, static_cast<hipStream_t>(stream), cu_seqlens_q, prefix_lens, bs,
                        (max_seqlen_q + kBM - 1) / kBM, plan);
     return check_launch("extend_plan_kernel");
 }

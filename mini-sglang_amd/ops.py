@@ -95,8 +95,10 @@ def paged_decode(
     chunk_dev: Optional[torch.Tensor] = None,
     kv_stream: bool = True,
     reuse_lens: Optional[torch.Tensor] = None,
+    plan: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """Decode attention for q [bs, Hq, D] over the paged pool; returns [bs, Hq, D] bf16.
+    plan: launch order from decode_plan for the same seq_lens / max_splits / chunk (ragged batches).
 
     kv_stream: read K/V with the non-temporal hint, except positions below reuse_lens[b] (prefix slots other
     requests share), which stay cacheable.  A pure performance hint."""
@@ -129,6 +131,9 @@ def paged_decode(
     elif chunk_tokens <= 0:
         _need(max_splits == 1, "chunk_tokens is required when max_splits > 1")
         chunk_tokens = 1 << 30  # one split covers any sequence
+    if plan is not None:
+        _dev_i32(plan, "plan")
+        _need(plan.numel() == bs * max_splits, "plan must have bs * max_splits entries")
     qs = q.stride(0) if bs > 1 else Hq * D
     os_ = out.stride(0) if bs > 1 else Hq * D
     _check(_lib.msgl_paged_decode(
@@ -139,7 +144,30 @@ def paged_decode(
         workspace.numel() * workspace.element_size() if workspace is not None else 0,
         bs, Hq, Hkv, D, page_size, float(scale), max_splits, int(chunk_tokens),
         chunk_dev.data_ptr() if chunk_dev is not None else None, 1 if kv_stream else 0,
-        reuse_lens.data_ptr() if reuse_lens is not None else None, _stream()))
+        reuse_lens.data_ptr() if reuse_lens is not None else None,
+        plan.data_ptr() if plan is not None else None, _stream()))
+    return out
+
+
+def decode_plan(seq_lens: torch.Tensor, max_splits: int, chunk_tokens: int = 0, chunk_dev: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None, sorted_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Launch order of paged_decode's (split, request) items for a ragged batch: full splits first, partial tails
+    by falling length.  Built on the device from seq_lens; one call per step serves every layer.  sorted_dev: device
+    word, 0 = write the identity order instead (decided at run time, for captured graphs)."""
+    _dev_i32(seq_lens, "seq_lens")
+    bs = seq_lens.numel()
+    if chunk_dev is not None:
+        _dev_i32(chunk_dev, "chunk_dev")
+    if sorted_dev is not None:
+        _dev_i32(sorted_dev, "sorted_dev")
+    if out is None:
+        out = torch.empty(bs * max_splits, dtype=torch.int32, device=seq_lens.device)
+    else:
+        _dev_i32(out, "out")
+        _need(out.numel() == bs * max_splits, "plan must have bs * max_splits entries")
+    _check(_lib.msgl_decode_plan(seq_lens.data_ptr(), bs, int(max_splits), int(chunk_tokens),
+                                 chunk_dev.data_ptr() if chunk_dev is not None else None,
+                                 sorted_dev.data_ptr() if sorted_dev is not None else None, out.data_ptr(), _stream()))
     return out
 
 
@@ -162,6 +190,48 @@ def pick_split(seq_lens_cpu_max: int, total_tokens: int, bs: int, max_splits: in
     floor_ = -(-max(seq_lens_cpu_max, 1) // max_splits)
     chunk = max(per_group, floor_, min_chunk)
     return -(-chunk // DECODE_TILE) * DECODE_TILE
+
+
+def planned_makespan(seq_lens, chunk: int, slots: int, group_overhead: int) -> int:
+    """Tokens the busiest of `slots` concurrently running work groups reads when the (request, split) items of
+    `seq_lens` cut at `chunk` are started longest first (what the hardware's in-order dispatch does with a launch
+    ordered by decode_plan): the full splits are dealt round robin, then every partial tail, by falling length,
+    goes to the group slot that is free first.  `group_overhead`: start-up and merge cost of one item, in tokens."""
+    import heapq
+
+    full = sum(s // chunk for s in seq_lens)
+    tails = sorted((s % chunk for s in seq_lens if s % chunk), reverse=True)
+    unit = chunk + group_overhead
+    base, extra = divmod(full, slots)
+    if not tails:
+        return (base + (1 if extra else 0)) * unit
+    if len(tails) <= slots - extra:  # every tail finds a slot that holds only `base` full splits
+        return max(base * unit + tails[0] + group_overhead, (base + 1) * unit if extra else 0)
+    loads = [(base + 1) * unit] * extra + [base * unit] * (slots - extra)
+    heapq.heapify(loads)
+    for t in tails:
+        heapq.heapreplace(loads, loads[0] + t + group_overhead)
+    return max(loads)
+
+
+def pick_split_planned(seq_lens, max_splits: int, local_kv_heads: int = 8, slots: int = 256) -> int:
+    """Tokens per split for a ragged batch launched in decode_plan order: the candidate (multiples of 256 tokens)
+    whose longest-first schedule on `slots` compute units finishes first.  `seq_lens`: host-side lengths."""
+    lens = [int(s) for s in seq_lens]
+    waves_per_head = max(1, 8 // max(1, min(8, local_kv_heads)))
+    lo = max(256, 64 * waves_per_head, -(-max(lens) // max_splits))
+    lo = -(-lo // 256) * 256
+    hi = max(lo, min(-(-max(lens) // 256) * 256, 8192))
+    overhead = 128 * waves_per_head  # a group's prologue + its share of the merge, in tokens of this shard's rows
+    step = 256 * max(1, (hi - lo) // (256 * 16))  # at most ~16 candidates
+    best, best_cost = lo, None
+    for chunk in range(lo, hi + 1, step):
+        cost = planned_makespan(lens, chunk, slots, overhead)
+        if sum(-(-s // chunk) for s in lens) > slots:
+            cost *= 1.1  # measured: launches that fit the chip in one round beat what the list schedule predicts for the rest
+        if best_cost is None or cost < best_cost:
+            best, best_cost = chunk, cost
+    return best
 
 
 # ----------------------------------------------------------------------------- extend

@@ -53,6 +53,8 @@ class DeviceDecodeLoop:
         if getattr(be, "decode_graph_vars", None) is None or bs not in getattr(be, "decode_graph_metadata", {}):
             be.init_cuda_graph_state(max(bs, getattr(mr.graph_runner, "max_bs", 0) if mr.graph_runner else 0))
             be.init_forward_metadata_capture_cuda_graph(bs, ForwardMode.DECODE)
+        if hasattr(be, "refresh_decode_plan"):
+            be.plan_refresh_in_graph = True  # the captured step prepares the batch itself: lengths change inside it
         self.graph = None
         self._capture()
 
@@ -68,6 +70,8 @@ class DeviceDecodeLoop:
         ops.prepare_decode(self.req_pool_indices, self.seq_lens, self.last_slots, self.free_pages, self.free_range,
                            mr.req_to_token_pool.req_to_token, self.positions, self.out_cache_loc, self.status, mr.page_size,
                            next_tokens=self.next_tokens, input_ids=self.input_ids)
+        if hasattr(mr.attn_backend, "refresh_decode_plan"):  # launch order for the lengths this step attends over
+            mr.attn_backend.refresh_decode_plan(self.bs, self.seq_lens)
         # greedy sampling on the vocabulary shard of each rank; the ranks exchange (value, index) pairs, not logits
         mr.model.forward_greedy(self.input_ids, self.positions, self.static_batch,
                                 lambda lg: ops.argmax(lg, return_values=True), out=self.next_tokens)

@@ -206,6 +206,27 @@ def extend_plan_ref(cu_seqlens_q, prefix_lens, max_seqlen_q: int, q_tile: int = 
     return items, cost
 
 
+def decode_plan_ref(seq_lens, max_splits: int, chunk: int, tile: int = 16):
+    """Work items of a split decode launch with their cost, for checking the device-built launch order (no
+    counterpart in the reference, whose decode loops over requests on the host, torch_attn_backend.py:146-180).
+    Item split * bs + b covers positions [split * chunk, min(S_b, (split + 1) * chunk)) of request b -- the last
+    of `max_splits` splits takes everything that is left -- and costs its number of `tile`-token tiles.
+    Returns (items, tiles) for the items that cover at least one position."""
+    bs = len(seq_lens)
+    chunk = max(tile, -(-chunk // tile) * tile)
+    items, cost = [], []
+    for split in range(max_splits):
+        for b in range(bs):
+            S = int(seq_lens[b])
+            if split >= min(-(-S // chunk), max_splits):
+                continue
+            t0 = split * chunk
+            t1 = S if split == max_splits - 1 else min(S, t0 + chunk)
+            items.append(split * bs + b)
+            cost.append(-(-(t1 - t0) // tile))
+    return items, cost
+
+
 def paged_attention_fp64(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, tok: torch.Tensor, scale: float,
                          q_positions: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Exact softmax(q K^T) V in float64 for ONE request: q [Sq, Hq, D], tok = its slot list [S].

@@ -30,8 +30,9 @@ def run(name, Hq, Hkv, ps, seq_lens, groups=None, prefix=None, layers=4, steps=2
     reuse = torch.tensor([prefix[g] for g in groups], dtype=torch.int32, device=dev) if groups is not None else None
     stream = os.environ.get("KV_STREAM", "1") == "1"
     ms_ = max(1, min(ms_, -(-max(seq_lens) // ch)))
+    plan = ops.decode_plan(sl, ms_, ch) if (os.environ.get("PLAN", "auto") == "1" or (os.environ.get("PLAN", "auto") == "auto" and max(seq_lens) > 1.25 * sum(seq_lens) / bs)) and ms_ > 1 else None
     f = lambda i: ops.paged_decode(q, pools[i % layers][0], pools[i % layers][1], r2t, idx, sl, D ** -0.5, ps, out=out, workspace=ws, max_splits=ms_, chunk_tokens=ch,
-                                   kv_stream=stream, reuse_lens=reuse if os.environ.get("REUSE", "1") == "1" else None)
+                                   kv_stream=stream, reuse_lens=reuse if os.environ.get("REUSE", "1") == "1" else None, plan=plan)
     for i in range(5): f(i)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -41,7 +42,7 @@ def run(name, Hq, Hkv, ps, seq_lens, groups=None, prefix=None, layers=4, steps=2
     ms = e0.elapsed_time(e1) / steps
     b = 2 * Hkv * D * 2 * sum(seq_lens)
     ub = 2 * Hkv * D * 2 * pt.unique_tokens
-    print(json.dumps(dict(name=name, bs=bs, Hq=Hq, Hkv=Hkv, ps=ps, tokens=sum(seq_lens), layers=layers, max_splits=ms_, chunk=ch, ms=round(ms, 4),
+    print(json.dumps(dict(name=name, bs=bs, Hq=Hq, Hkv=Hkv, ps=ps, tokens=sum(seq_lens), layers=layers, max_splits=ms_, chunk=ch, planned=plan is not None, ms=round(ms, 4),
                           GBps=round(b / ms / 1e6, 1), unique_GBps=round(ub / ms / 1e6, 1))), flush=True)
     del pools
 

@@ -122,11 +122,14 @@ def test_e2e_hip_vs_oracle_on_same_device():
     assert torch.equal(hip["req_to_token_rows"], ref["req_to_token_rows"])
 
 
+@pytest.mark.parametrize("lens", [[15, 16, 33, 200, 1], [1500, 16, 700, 3000, 1]], ids=["short", "ragged-multi-split"])
 @pytest.mark.parametrize("ps", [1, 16])
-def test_device_chained_decode_equals_host_prepared_steps(ps):
+def test_device_chained_decode_equals_host_prepared_steps(ps, lens):
     """k decode steps chained on the GPU (msgl_prepare_decode -> forward -> argmax in one hipGraph, no host work
     between steps) leave the same tokens, page table, last slots and allocator state as k steps prepared on the
-    host by BatchInfo.prepare_for_decode."""
+    host by BatchInfo.prepare_for_decode.  The second batch is ragged and long enough for several splits per request:
+    both sides then launch their decode kernels in planned order (the eager side from a per-step plan, the captured
+    side from the plan it refreshes inside the graph)."""
     from mini_sglang_amd.runtime import decode_loop
     from mini_sglang_amd.runtime.device_decode import DeviceDecodeLoop
     from mini_sglang_amd.runtime.qwen3 import Qwen3Config
@@ -134,8 +137,8 @@ def test_device_chained_decode_equals_host_prepared_steps(ps):
     def build():
         torch.manual_seed(1234)  # the harness fills the K/V pools from torch's generator: same contexts in both runs
         cfg = Qwen3Config(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
-                          intermediate_size=512, vocab_size=2048, max_position_embeddings=1024, tie_word_embeddings=False)
-        return decode_loop.build_decode_state(cfg, 5, 0, ps, 64, use_graph=False, seed=3, seq_lens=[15, 16, 33, 200, 1])
+                          intermediate_size=512, vocab_size=2048, max_position_embeddings=4096, tie_word_embeddings=False)
+        return decode_loop.build_decode_state(cfg, 5, 0, ps, 64, use_graph=False, seed=3, seq_lens=list(lens))
 
     steps = 24
     mr_a, batch_a = build()

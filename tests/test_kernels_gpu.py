@@ -160,6 +160,46 @@ def test_decode_full_size_properties():
         assert_close_fp64(a[r].cpu(), exact, f"request {r} of the headline batch")
 
 
+def test_decode_plan_orders_items():
+    """The device-built launch order of a ragged decode batch against its restatement: same items, non-increasing
+    tile counts, -1 tail; chunk from a host value and from device memory; the run-time switch to the identity."""
+    ops = _ops()
+    for lens, max_splits, chunk in [([5000, 100, 900, 33, 2048, 1, 4097, 16, 17], 16, 512),
+                                    ([1], 1, 16), ([70000, 3], 8, 4096),   # the last split takes a long tail
+                                    ([1 + (37 * i) % 3000 for i in range(1500)], 4, 1024)]:
+        sl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+        items, tiles = orc.decode_plan_ref(lens, max_splits, chunk)
+        cost = dict(zip(items, tiles))
+        for kw in (dict(chunk_tokens=chunk), dict(chunk_dev=torch.tensor([chunk], dtype=torch.int32, device=DEV))):
+            plan = ops.decode_plan(sl, max_splits, **kw).cpu()
+            assert plan.numel() == len(lens) * max_splits and (plan[len(items):] == -1).all()
+            got = plan[: len(items)].tolist()
+            assert sorted(got) == sorted(items)
+            got_cost = [min(cost[i], 2047) for i in got]
+            assert got_cost == sorted(got_cost, reverse=True)
+        off = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ident = ops.decode_plan(sl, max_splits, chunk_tokens=chunk, sorted_dev=off).cpu()
+        assert torch.equal(ident, torch.arange(len(lens) * max_splits, dtype=torch.int32))
+        on = torch.ones(1, dtype=torch.int32, device=DEV)
+        assert sorted(ops.decode_plan(sl, max_splits, chunk_tokens=chunk, sorted_dev=on).cpu()[: len(items)].tolist()) == sorted(items)
+
+
+@pytest.mark.parametrize("Hq,Hkv,page_size", [(32, 8, 16), (8, 1, 64), (16, 8, 1)])
+def test_decode_planned_launch_is_bit_identical(Hq, Hkv, page_size):
+    """The plan only permutes work groups: a ragged batch gives the same bits with and without it, and matches
+    the oracle; the split size comes from the host-side schedule model the backend uses for such batches."""
+    ops = _ops()
+    seq = [5000, 100, 900, 33, 2048, 1, 4097, 16, 17, 3000]
+    case = build_case(Hq, Hkv, page_size, seq, seed=61 + Hq)
+    chunk = ops.pick_split_planned(seq, 16, Hkv)
+    assert chunk % 16 == 0 and -(-max(seq) // chunk) <= 16
+    for max_splits, ch in [(16, chunk), (64, 128)]:
+        base = run_decode(case, page_size, max_splits=max_splits, chunk_tokens=ch)
+        check_decode(case, base)
+        plan = ops.decode_plan(case["seq_lens"].to(DEV), max_splits, ch)
+        assert torch.equal(run_decode(case, page_size, max_splits=max_splits, chunk_tokens=ch, plan=plan), base)
+
+
 def test_decode_long_context_split():
     case = build_case(8, 1, 64, [20000, 3], seed=9)
     check_decode(case, run_decode(case, 64, max_splits=128, chunk_tokens=256))
