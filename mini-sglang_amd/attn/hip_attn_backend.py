@@ -63,7 +63,6 @@ class HipAttnBackend(AttentionBackend):
         self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count if torch.cuda.is_available() else 256
         self.decode_graph_vars: Optional[dict] = None
         self.decode_graph_metadata: Dict[int, HipAttnMetadata] = {}
-        self.plan_refresh_in_graph = False
 
     # ------------------------------------------------------------------ helpers
     def _workspace_for(self, bs: int, Hq: int, D: int, max_splits: int) -> Optional[torch.Tensor]:
@@ -178,14 +177,13 @@ class HipAttnBackend(AttentionBackend):
             chunk, ragged = self._decode_split(seq_lens_cpu, bs, md.max_splits)
             self.decode_graph_vars["chunk"].fill_(chunk)
             self.decode_graph_vars["plan_sorted"].fill_(1 if ragged else 0)
-            if not self.plan_refresh_in_graph:
-                self.refresh_decode_plan(bs, seq_lens)
+            self.refresh_decode_plan(bs, seq_lens)
         self.forward_metadata = md
 
     def refresh_decode_plan(self, bs: int, seq_lens: torch.Tensor) -> None:
-        """Rewrite the static launch order from the lengths now in `seq_lens` (device).  Called by the replay hook;
-        a runner whose captured step changes the lengths itself (device-side batch preparation) sets
-        ``plan_refresh_in_graph`` and calls this inside the step, after the lengths are final."""
+        """Rewrite the static launch order from the lengths now in `seq_lens` (device).  The replay hook calls it;
+        a runner whose captured step changes the lengths itself (device-side batch preparation) calls it once more
+        inside the step, after the lengths are final."""
         md = self.decode_graph_metadata[bs]
         if md.decode_plan is not None:
             ops.decode_plan(seq_lens[:bs], md.max_splits, chunk_dev=md.chunk_dev, out=md.decode_plan,

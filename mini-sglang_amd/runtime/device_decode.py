@@ -53,8 +53,6 @@ class DeviceDecodeLoop:
         if getattr(be, "decode_graph_vars", None) is None or bs not in getattr(be, "decode_graph_metadata", {}):
             be.init_cuda_graph_state(max(bs, getattr(mr.graph_runner, "max_bs", 0) if mr.graph_runner else 0))
             be.init_forward_metadata_capture_cuda_graph(bs, ForwardMode.DECODE)
-        if hasattr(be, "refresh_decode_plan"):
-            be.plan_refresh_in_graph = True  # the captured step prepares the batch itself: lengths change inside it
         self.graph = None
         self._capture()
 
