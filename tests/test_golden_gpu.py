@@ -134,11 +134,11 @@ def test_device_chained_decode_equals_host_prepared_steps(ps, lens):
     from mini_sglang_amd.runtime.device_decode import DeviceDecodeLoop
     from mini_sglang_amd.runtime.qwen3 import Qwen3Config
 
-    def build():
+    def build(use_graph=False):
         torch.manual_seed(1234)  # the harness fills the K/V pools from torch's generator: same contexts in both runs
         cfg = Qwen3Config(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
                           intermediate_size=512, vocab_size=2048, max_position_embeddings=4096, tie_word_embeddings=False)
-        return decode_loop.build_decode_state(cfg, 5, 0, ps, 64, use_graph=False, seed=3, seq_lens=list(lens))
+        return decode_loop.build_decode_state(cfg, 5, 0, ps, 64, use_graph=use_graph, seed=3, seq_lens=list(lens))
 
     steps = 24
     mr_a, batch_a = build()
@@ -158,6 +158,14 @@ def test_device_chained_decode_equals_host_prepared_steps(ps, lens):
     for ra, rb in zip(batch_a.reqs, batch_b.reqs):
         n = len(ra.token_ids)
         assert torch.equal(mr_a.req_to_token_pool.req_to_token[ra.req_pool_idx, :n], mr_b.req_to_token_pool.req_to_token[rb.req_pool_idx, :n])
+    # and the two kinds of captured steps mixed on one backend: chained steps, then host-prepared graph replays
+    mr_c, batch_c = build(use_graph=True)
+    loop_c = DeviceDecodeLoop(mr_c, batch_c, max_steps=32)
+    loop_c.run(10)
+    loop_c.sync_host()
+    decode_loop.decode_steps(mr_c, batch_c, steps - 10)
+    for ra, rc in zip(batch_a.reqs, batch_c.reqs):
+        assert ra.token_ids == rc.token_ids
 
 
 @pytest.mark.parametrize("ps", [1, 16])
