@@ -125,3 +125,32 @@ def test_unknown_backend_name():
         server_args = type("A", (), {"attention_backend": "fa3"})()
     with pytest.raises(ValueError, match="Unsupported attention backend"):
         ModelRunner.init_attn_backend(Stub())
+
+
+def test_planned_split_model():
+    """Host-side schedule model behind the split size of ragged decode batches: exact on hand-checkable cases, and
+    the picked size always lets the longest request fit its splits."""
+    from mini_sglang_amd import ops
+
+    # 4 slots, chunk 100, no overhead: 6 full splits (two slots hold 2), tails 50 and 30 go to the slots that hold 1
+    assert ops.planned_makespan([250, 230, 100, 100], 100, 4, 0) == 200
+    # every tail finds an empty slot
+    assert ops.planned_makespan([50, 30, 20], 100, 4, 0) == 50
+    # more tails than free slots: the smallest ones queue behind the earliest finishers
+    assert ops.planned_makespan([90, 80, 10, 10, 10], 100, 2, 0) == 100
+    assert ops.planned_makespan([100] * 8, 100, 4, 5) == 2 * 105
+    for lens, max_splits, kv_heads in [([5000, 100, 900, 33, 2048, 1], 16, 8), ([131072, 7], 512, 1), ([300] * 40 + [9000], 8, 2)]:
+        chunk = ops.pick_split_planned(lens, max_splits, kv_heads, 256)
+        assert chunk % 256 == 0 and -(-max(lens) // chunk) <= max_splits
+
+
+def test_decode_and_extend_plan_restatements():
+    """The numpy-free restatements the GPU tests check the device-built launch orders against."""
+    from oracle import torch_oracle as orc
+
+    items, cost = orc.decode_plan_ref([40, 16, 1], max_splits=2, chunk=16)
+    # request 0: split 0 = 16 tokens, split 1 (the last) takes the remaining 24; requests 1, 2: one split
+    assert dict(zip(items, cost)) == {0: 1, 1: 1, 2: 1, 3: 2}
+    items, cost = orc.extend_plan_ref([0, 300, 301], [64, 1000], 300)
+    # 3 query tiles per request slot; request 0: 300 rows on a 64 prefix; request 1: one row on 1000
+    assert dict(zip(items, cost)) == {0: 3, 1: 5, 2: 6, 3: 16}
