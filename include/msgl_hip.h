@@ -88,6 +88,11 @@ int msgl_store_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stri
  * plan: NULL (work groups in split-major order), or the bs * max_splits int32 entries
  *   msgl_decode_plan wrote for these very seq_lens / max_splits / chunk: the launch order
  *   for ragged batches.  Scheduling only, never changes results.
+ * start_lens / extra_splits (both NULL, or int32 [bs]): request b's positions below start_lens[b]
+ *   (a multiple of 16 when page_size % 16 == 0) are not read by this kernel; another kernel
+ *   (msgl_shared_prefix_decode) has put extra_splits[b] partial results for them into the
+ *   workspace slots behind this kernel's ceil((seq_len - start) / chunk) own ones, and the merge
+ *   covers both.  Requires ceil((seq_len - start) / chunk) + extra_splits[b] <= max_splits.
  * workspace: >= msgl_paged_decode_workspace_bytes(...) bytes of device memory,
  *   16-byte aligned; contents are scratch.
  * Supported: D == 128; Hq/Hkv in {1, 2, 4, 8}; Hkv in {1, 2, 4, 8}.
@@ -103,6 +108,7 @@ int msgl_paged_decode(const void* q, int64_t q_stride,
                       int bs, int Hq, int Hkv, int D, int page_size, float scale,
                       int max_splits, int chunk_tokens, const int32_t* chunk_dev,
                       int kv_stream, const int32_t* reuse_lens, const int32_t* plan,
+                      const int32_t* start_lens, const int32_t* extra_splits,
                       void* stream);
 
 /* Launch order of msgl_paged_decode's (split, request) work items for a batch of unequal
@@ -115,7 +121,39 @@ int msgl_paged_decode(const void* q, int64_t q_stride,
  * captured graph serves uniform and ragged batches. */
 int msgl_decode_plan(const int32_t* seq_lens, int bs, int max_splits,
                      int chunk_tokens, const int32_t* chunk_dev,
-                     const int32_t* sorted_dev, int32_t* plan, void* stream);
+                     const int32_t* sorted_dev, const int32_t* start_lens,
+                     int32_t* plan, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Decode attention over a radix prefix that several requests of the batch share
+ * (rows of req_to_token that start with the same slots, batch_info.py:184-186,
+ * 215-219), computed ONCE per group instead of once per request: the decode
+ * queries of the group's members, all heads of a kv head, form the rows of a
+ * matrix product against the shared keys (the extend kernel's tile loop), and the
+ * result goes, as split partials, into the decode workspace.  Call it before
+ * msgl_paged_decode on the same stream, workspace, seq_lens, max_splits and chunk;
+ * that call then gets start_lens[b] = the group's prefix length (0 for requests in
+ * no group) and extra_splits[b] = ceil(prefix / key_chunk), skips those positions
+ * and merges these partials with its own.  The reference has no counterpart: its
+ * backends read a shared prefix once per request.
+ * Group g = requests group_first[g] .. group_first[g] + group_count[g] - 1 of the
+ * batch (consecutive), sharing positions [0, group_prefix[g]) of their req_to_token
+ * rows; all int32 device arrays of num_groups entries.  max_members / max_prefix:
+ * host-side upper bounds (grid size).  key_chunk: keys per work group, a multiple
+ * of 64.
+ * ------------------------------------------------------------------------- */
+int msgl_shared_prefix_decode(const void* q, int64_t q_stride,
+                              const void* k_cache, const void* v_cache, int64_t cache_stride,
+                              const int32_t* req_to_token, int64_t r2t_stride,
+                              const int32_t* req_pool_indices,
+                              const int32_t* seq_lens, const int32_t* start_lens,
+                              const int32_t* group_first, const int32_t* group_count,
+                              const int32_t* group_prefix, int num_groups,
+                              int max_members, int max_prefix, int key_chunk,
+                              void* workspace, size_t workspace_bytes,
+                              int bs, int Hq, int Hkv, int D, float scale,
+                              int max_splits, int chunk_tokens, const int32_t* chunk_dev,
+                              void* stream);
 
 /* ---------------------------------------------------------------------------
  * Paged extend (prefill) attention, variable-length queries, bottom-right causal.

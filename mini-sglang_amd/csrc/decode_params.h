@@ -1,0 +1,58 @@
+// Launch parameters and split arithmetic of the decode path, shared by the kernels that write split
+// partials (the per-request gather and the shared-prefix kernel) and the ones that plan and merge them.
+#pragma once
+#include "msgl_common.h"
+
+namespace msgl {
+
+constexpr int kTile = 16;    // tokens per wave iteration
+constexpr int kWaves = 8;    // waves per work group
+constexpr int kD = 128;      // head dim
+constexpr float kNegBig = -1.0e30f;
+
+struct DecodeParams {
+    const uint16_t* q;
+    int64_t q_stride;
+    const uint16_t* kc;
+    const uint16_t* vc;
+    int64_t cache_stride;
+    const int32_t* r2t;
+    int64_t r2t_stride;
+    const int32_t* req_idx;
+    const int32_t* seq_lens;
+    uint16_t* out;
+    int64_t out_stride;
+    float* ws_o;   // [bs, max_splits, Hq, 128] unnormalised partial outputs
+    float* ws_ml;  // [bs, max_splits, Hq, 2]   (running max in log2 units, running sum)
+    const int32_t* chunk_dev;
+    const int32_t* reuse_lens;  // per request: positions below this may be shared with other requests
+    const int32_t* plan;        // optional launch order of the (split, request) items, see decode_plan_kernel
+    const int32_t* start_lens;  // optional, per request: leading positions another kernel attends over (shared prefix)
+    const int32_t* extra_splits;  // optional, per request: partial-result slots that kernel fills, after this one's
+    int kv_stream;              // 0: every K/V load is cached; 1: loads at or above reuse_lens are non-temporal
+    int chunk;
+    int bs, Hq, max_splits;
+    float scale_log2e;
+};
+
+// Tokens per split: a positive multiple of the tile so that tiles never straddle a page.
+__device__ __forceinline__ int split_chunk(const DecodeParams& p) {
+    const int c = p.chunk_dev ? *p.chunk_dev : p.chunk;
+    return max(kTile, (c + kTile - 1) & ~(kTile - 1));
+}
+
+// What request b asks of the gather kernel: positions [start, S) in `nsplit` splits of `chunk` tokens (the last of
+// max_splits takes whatever is left), and `extra` more partial results in slots nsplit .. nsplit + extra - 1.
+struct SplitInfo {
+    int start, S, nsplit, extra;
+};
+__device__ __forceinline__ SplitInfo split_info(const DecodeParams& p, int b, int chunk) {
+    SplitInfo r;
+    r.S = p.seq_lens[b];
+    r.start = p.start_lens ? p.start_lens[b] : 0;
+    r.extra = p.extra_splits ? p.extra_splits[b] : 0;
+    r.nsplit = min((r.S - r.start + chunk - 1) / chunk, p.max_splits);
+    return r;
+}
+
+}  // namespace msgl

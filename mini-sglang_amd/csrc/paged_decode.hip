@@ -23,45 +23,12 @@
 //     sequence lengths; partial results go to a caller-provided workspace and a second
 //     small kernel merges them (requests that fit one split are written directly).
 #include "msgl_common.h"
+#include "decode_params.h"
 #include "plan_sort.h"
 
 #include <type_traits>
 
 namespace msgl {
-
-constexpr int kTile = 16;    // tokens per wave iteration
-constexpr int kWaves = 8;    // waves per work group
-constexpr int kD = 128;      // head dim
-constexpr float kNegBig = -1.0e30f;
-
-struct DecodeParams {
-    const uint16_t* q;
-    int64_t q_stride;
-    const uint16_t* kc;
-    const uint16_t* vc;
-    int64_t cache_stride;
-    const int32_t* r2t;
-    int64_t r2t_stride;
-    const int32_t* req_idx;
-    const int32_t* seq_lens;
-    uint16_t* out;
-    int64_t out_stride;
-    float* ws_o;   // [bs, max_splits, Hq, 128] unnormalised partial outputs
-    float* ws_ml;  // [bs, max_splits, Hq, 2]   (running max in log2 units, running sum)
-    const int32_t* chunk_dev;
-    const int32_t* reuse_lens;  // per request: positions below this may be shared with other requests
-    const int32_t* plan;        // optional launch order of the (split, request) items, see decode_plan_kernel
-    int kv_stream;              // 0: every K/V load is cached; 1: loads at or above reuse_lens are non-temporal
-    int chunk;
-    int bs, Hq, max_splits;
-    float scale_log2e;
-};
-
-// Tokens per split: a positive multiple of the tile so that tiles never straddle a page.
-__device__ __forceinline__ int split_chunk(const DecodeParams& p) {
-    const int c = p.chunk_dev ? *p.chunk_dev : p.chunk;
-    return max(kTile, (c + kTile - 1) & ~(kTile - 1));
-}
 
 __device__ __forceinline__ uint4 ld16(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
 // K/V row load.  NT = non-temporal hint: rows that no other request re-reads in this launch should not
@@ -99,11 +66,11 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
     }
     const int split = item / p.bs;
     const int b = item - split * p.bs;
-    const int S = p.seq_lens[b];
     const int chunk = split_chunk(p);
-    const int nsplit = min((S + chunk - 1) / chunk, p.max_splits);
+    const SplitInfo si = split_info(p, b, chunk);
+    const int S = si.S, nsplit = si.nsplit;
     if (split >= nsplit) return;
-    const int t0 = split * chunk;
+    const int t0 = si.start + split * chunk;
     const int t1 = (split == p.max_splits - 1) ? S : min(S, t0 + chunk);  // last split takes the tail
     const int ntiles = (t1 - t0 + kTile - 1) / kTile;
 
@@ -393,7 +360,7 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
     if (sub != 0) return;
 
     // the first wave of every kv head merges the WPH partial states and writes the result
-    const bool final_out = (nsplit == 1);
+    const bool final_out = (nsplit == 1 && si.extra == 0);
 #pragma unroll
     for (int idx = lane * 2; idx < G * kD; idx += 128) {
         const int g = idx / kD, d = idx - g * kD;
@@ -438,11 +405,10 @@ __global__ __launch_bounds__(kPlanThreads) void decode_plan_kernel(DecodeParams 
     const int chunk = split_chunk(p);
     auto tiles = [&](int i) -> int {
         const int split = i / p.bs, b = i - split * p.bs;
-        const int S = p.seq_lens[b];
-        const int nsplit = min((S + chunk - 1) / chunk, p.max_splits);
-        if (split >= nsplit) return -1;
-        const int t0 = split * chunk;
-        const int t1 = (split == p.max_splits - 1) ? S : min(S, t0 + chunk);
+        const SplitInfo si = split_info(p, b, chunk);
+        if (split >= si.nsplit) return -1;
+        const int t0 = si.start + split * chunk;
+        const int t1 = (split == p.max_splits - 1) ? si.S : min(si.S, t0 + chunk);
         return (t1 - t0 + kTile - 1) / kTile;
     };
     plan_sort_descending(p.bs * p.max_splits, tiles, plan, bins, part);
@@ -462,10 +428,9 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_merge_kernel(DecodeParam
     __shared__ float part[NW][kD];
     const int b = blockIdx.x / p.Hq;
     const int hq = blockIdx.x - b * p.Hq;
-    const int S = p.seq_lens[b];
-    const int chunk = split_chunk(p);
-    const int nsplit = min((S + chunk - 1) / chunk, p.max_splits);
-    if (nsplit <= 1) return;  // written directly by the main kernel
+    const SplitInfo si = split_info(p, b, split_chunk(p));
+    const int nsplit = min(si.nsplit + si.extra, p.max_splits);  // this kernel's partials, then the shared-prefix kernel's
+    if (nsplit <= 1 && si.extra == 0) return;  // written directly by the main kernel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row0 = ((int64_t)b * p.max_splits) * p.Hq + hq;
     // running max over splits
@@ -545,10 +510,9 @@ __global__ __launch_bounds__(256) void paged_decode_merge_small_kernel(DecodePar
     if (row >= p.bs * p.Hq) return;
     const int b = row / p.Hq;
     const int hq = row - b * p.Hq;
-    const int S = p.seq_lens[b];
-    const int chunk = split_chunk(p);
-    const int nsplit = min((S + chunk - 1) / chunk, p.max_splits);
-    if (nsplit <= 1) return;  // written directly by the main kernel
+    const SplitInfo si = split_info(p, b, split_chunk(p));
+    const int nsplit = min(si.nsplit + si.extra, p.max_splits);
+    if (nsplit <= 1 && si.extra == 0) return;  // written directly by the main kernel
     const int64_t row0 = ((int64_t)b * p.max_splits) * p.Hq + hq;
     const float2 ml = lane < nsplit ? *reinterpret_cast<const float2*>(p.ws_ml + (row0 + (int64_t)lane * p.Hq) * 2)
                                     : make_float2(kNegBig, 0.f);
@@ -618,7 +582,7 @@ extern "C" int msgl_paged_decode(const void* q, int64_t q_stride, const void* k_
                                  int64_t out_stride, void* workspace, size_t workspace_bytes, int bs, int Hq, int Hkv,
                                  int D, int page_size, float scale, int max_splits, int chunk_tokens,
                                  const int32_t* chunk_dev, int kv_stream, const int32_t* reuse_lens, const int32_t* plan,
-                                 void* stream) {
+                                 const int32_t* start_lens, const int32_t* extra_splits, void* stream) {
     if (bs == 0) return MSGL_OK;
     MSGL_REQUIRE(bs > 0, "msgl_paged_decode: bs=%d", bs);
     MSGL_REQUIRE(cache_stride <= (int64_t)1 << 27, "msgl_paged_decode: cache_stride %lld too large", (long long)cache_stride);
@@ -626,6 +590,8 @@ extern "C" int msgl_paged_decode(const void* q, int64_t q_stride, const void* k_
     MSGL_REQUIRE(Hkv > 0 && Hq % Hkv == 0, "msgl_paged_decode: Hq=%d not a multiple of Hkv=%d", Hq, Hkv);
     MSGL_REQUIRE(page_size >= 1, "msgl_paged_decode: page_size=%d", page_size);
     MSGL_REQUIRE(max_splits >= 1 && max_splits <= 4096, "msgl_paged_decode: max_splits=%d", max_splits);
+    MSGL_REQUIRE(extra_splits == nullptr || (start_lens != nullptr && max_splits >= 2),
+                 "msgl_paged_decode: extra_splits needs start_lens and room for them (max_splits >= 2)");
     MSGL_REQUIRE(chunk_dev != nullptr || (chunk_tokens > 0 && chunk_tokens % kTile == 0),
                  "msgl_paged_decode: chunk_tokens=%d must be a positive multiple of %d", chunk_tokens, kTile);
     MSGL_REQUIRE(q && k_cache && v_cache && req_to_token && req_pool_indices && seq_lens && out,
@@ -661,6 +627,8 @@ extern "C" int msgl_paged_decode(const void* q, int64_t q_stride, const void* k_
     p.chunk_dev = chunk_dev;
     p.reuse_lens = reuse_lens;
     p.plan = plan;
+    p.start_lens = start_lens;
+    p.extra_splits = extra_splits;
     p.kv_stream = kv_stream ? 1 : 0;
     p.chunk = chunk_tokens;
     p.bs = bs;
@@ -679,7 +647,7 @@ extern "C" int msgl_paged_decode(const void* q, int64_t q_stride, const void* k_
 }
 
 extern "C" int msgl_decode_plan(const int32_t* seq_lens, int bs, int max_splits, int chunk_tokens, const int32_t* chunk_dev,
-                                const int32_t* sorted_dev, int32_t* plan, void* stream) {
+                                const int32_t* sorted_dev, const int32_t* start_lens, int32_t* plan, void* stream) {
     if (bs == 0) return MSGL_OK;
     MSGL_REQUIRE(bs > 0 && max_splits >= 1 && max_splits <= 4096, "msgl_decode_plan: bs=%d max_splits=%d", bs, max_splits);
     MSGL_REQUIRE((int64_t)bs * max_splits <= 0x7fffffff, "msgl_decode_plan: too many items");
@@ -688,6 +656,7 @@ extern "C" int msgl_decode_plan(const int32_t* seq_lens, int bs, int max_splits,
     MSGL_REQUIRE(seq_lens && plan, "msgl_decode_plan: null pointer argument");
     DecodeParams p = {};
     p.seq_lens = seq_lens;
+    p.start_lens = start_lens;
     p.chunk_dev = chunk_dev;
     p.chunk = chunk_tokens;
     p.bs = bs;

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "msgl_common.h"
+#include "decode_params.h"
 #include "plan_sort.h"
 
 namespace msgl {
@@ -60,6 +61,20 @@ struct ExtendParams {
     int group;  // query heads per kv head
     float scale_log2e;
     const int32_t* plan;  // optional: (request, query tile) items in launch order, see extend_plan_kernel
+};
+
+// Shared-prefix mode (GROUPED): the "query rows" of a work group are the decode queries of the requests that share
+// one radix prefix, (member, head of the GQA group) pairs of one kv head, and the keys are a slice of that prefix,
+// visible to every row.  The result is not an output row but a split partial (unnormalised O, running max, sum)
+// in the decode workspace, in the slots behind the request's own splits, for the decode merge kernel.
+struct GroupedParams {
+    const int32_t* first;   // per group: index of its first request in the batch (members are consecutive)
+    const int32_t* count;   // per group: number of member requests
+    const int32_t* prefix;  // per group: shared prefix length in tokens
+    int key_chunk;          // keys per work group (a multiple of 64)
+    int key_splits;         // ceil(longest prefix / key_chunk)
+    int row_tiles;          // ceil(most members * heads per kv head / 128)
+    DecodeParams dec;       // seq_lens, start_lens, split size, max_splits, Hq, workspace of the decode launch
 };
 
 __device__ __forceinline__ bf16x8_t as_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
@@ -137,18 +152,52 @@ constexpr int SG_VALU = 0x002, SG_MFMA = 0x008, SG_VMEMREAD = 0x020, SG_DSREAD =
 // 2: the ring slot of tile t+1 is only free once every wave has finished tile t-1, so the write sits between two
 // barriers; 72 KiB lets two 4-wave groups share a CU, which hides the serial start-up (page table -> rows ->
 // LDS -> first S^T) that dominates when a request has only a handful of key tiles.
-template <int NH, int ST>
-__global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams p) {
+template <int NH, int ST, bool GROUPED = false>
+__global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams p, GroupedParams gp) {
+    static_assert(!GROUPED || NH == 1, "rows of a shared-prefix work group already span the heads of the kv head");
     constexpr int KPT = 4 / NH;          // keys staged per thread and tile
     constexpr int KSTEP = 16 * NH;       // distance between a thread's staged keys
     extern __shared__ __attribute__((aligned(256))) char lds[];  // ST * kTileBytes
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31;  // query column of the S^T / O^T tiles
+    const int h = lane >> 5;
+    // what the tile loop needs, set by either mode: keys are positions [0, kv_len) of r2t_row, row visibility ends at qpos
+    int hk, hq, kv_len, nkt, qpos, full_nkt, my_nkt, g_member = 0, g_split = 0;
+    int64_t out_row = 0;
+    bool qvalid;
+    const int32_t* r2t_row;
+    const uint16_t* qp;
+    if constexpr (GROUPED) {
+        int idx = blockIdx.x;
+        hk = idx % p.hkv, idx /= p.hkv;
+        g_split = idx % gp.key_splits, idx /= gp.key_splits;
+        const int rt = idx % gp.row_tiles;
+        const int gi = idx / gp.row_tiles;
+        const int first = gp.first[gi], rows = gp.count[gi] * p.group, pre = gp.prefix[gi];
+        const int key0 = g_split * gp.key_chunk;
+        if (rt * kBM >= rows || key0 >= pre) return;
+        kv_len = min(pre - key0, gp.key_chunk);  // positions are counted from key0
+        nkt = (kv_len + kBN - 1) / kBN;
+        const int row0 = rt * kBM + (wave & 3) * 32;
+        const int row = row0 + n;
+        qvalid = row < rows;
+        g_member = first + (qvalid ? row / p.group : 0);
+        hq = hk * p.group + (qvalid ? row % p.group : 0);
+        qpos = kv_len - 1;  // no causal structure: every row sees the whole slice
+        full_nkt = kv_len / kBN;
+        my_nkt = row0 < rows ? nkt : 0;
+        r2t_row = p.r2t + (int64_t)p.req_idx[first] * p.r2t_stride + key0;
+        qp = p.q + (int64_t)g_member * p.q_stride + hq * kHD + h * 8;
+    } else {
 
     // Block order: the last (heaviest under the causal mask) query tile of every request and head first,
     // so the long blocks start early and the short ones fill the tail.  The kv head varies fastest: with
     // 8 kv heads the blocks that share a K/V stream run on the same XCD back to back.
     const int hsets = p.group / NH;  // work groups per (kv head, query tile)
     const int idx = blockIdx.x;
-    const int hk = idx % p.hkv;
+    hk = idx % p.hkv;
     const int hs = (idx / p.hkv) % hsets;
     int b = (idx / (p.hkv * hsets)) % p.bs;
     int qt = p.tiles_per_req - 1 - idx / (p.hkv * hsets * p.bs);
@@ -162,32 +211,25 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
     const int Sq = p.cu_q[b + 1] - q0;
     if (qt * kBM >= Sq) return;
     const int prefix = p.prefix[b];
-    const int kv_len = min(prefix + Sq, prefix + qt * kBM + kBM);  // keys any row of this block may see
-    const int nkt = (kv_len + kBN - 1) / kBN;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hq = hk * p.group + hs * NH + (wave >> 2);
-    const int n = lane & 31;  // query column of the S^T / O^T tiles
-    const int h = lane >> 5;
+    kv_len = min(prefix + Sq, prefix + qt * kBM + kBM);  // keys any row of this block may see
+    nkt = (kv_len + kBN - 1) / kBN;
+    hq = hk * p.group + hs * NH + (wave >> 2);
     const int row0 = qt * kBM + (wave & 3) * 32;  // first query row of this wave
     const int qrow = row0 + n;
-    const bool qvalid = qrow < Sq;
-    const int qpos = prefix + qrow;  // last key position this lane's query may see
+    qvalid = qrow < Sq;
+    qpos = prefix + qrow;  // last key position this lane's query may see
     // tiles [0, full_nkt) are visible to every row of the wave, [full_nkt, my_nkt) partly, the rest not at all
-    const int full_nkt = (prefix + row0 + 1) / kBN;
-    const int my_nkt = (row0 < Sq) ? min(nkt, (prefix + row0 + 31) / kBN + 1) : 0;
-
-    const int32_t* r2t_row = p.r2t + (int64_t)p.req_idx[b] * p.r2t_stride;
+    full_nkt = (prefix + row0 + 1) / kBN;
+    my_nkt = (row0 < Sq) ? min(nkt, (prefix + row0 + 31) / kBN + 1) : 0;
+    r2t_row = p.r2t + (int64_t)p.req_idx[b] * p.r2t_stride;
+    qp = p.q + (int64_t)(q0 + (qvalid ? qrow : 0)) * p.q_stride + hq * kHD + h * 8;
+    out_row = q0 + qrow;
+    }
 
     // Q^T fragments: B operand, lane (n, h) holds Q[n][16*ks + 8*h .. +8)
     uint4 qf[8];
-    {
-        const uint16_t* qp = p.q + (int64_t)(q0 + (qvalid ? qrow : 0)) * p.q_stride + hq * kHD + h * 8;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = qvalid ? *reinterpret_cast<const uint4*>(qp + ks * 16) : make_uint4(0, 0, 0, 0);
-    }
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = qvalid ? *reinterpret_cast<const uint4*>(qp + ks * 16) : make_uint4(0, 0, 0, 0);
 
     f32x16_t o[4];
 #pragma unroll
@@ -467,8 +509,23 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
 
     l += __shfl_xor(l, 32);
     if (!qvalid) return;
+    if constexpr (GROUPED) {
+        // split partial of (member, head): slot = the member's own split count + this key slice
+        const DecodeParams& dp = gp.dec;
+        const SplitInfo si = split_info(dp, g_member, split_chunk(dp));
+        const int64_t row = ((int64_t)g_member * dp.max_splits + si.nsplit + g_split) * dp.Hq + hq;
+        float* po = dp.ws_o + row * kHD;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                *reinterpret_cast<float4*>(po + d * 32 + 8 * rr + 4 * h) =
+                    make_float4(o[d][4 * rr], o[d][4 * rr + 1], o[d][4 * rr + 2], o[d][4 * rr + 3]);
+        if (h == 0) *reinterpret_cast<float2*>(dp.ws_ml + row * 2) = make_float2(m, l);
+        return;
+    }
     const float inv = 1.0f / l;
-    uint16_t* op = p.out + (int64_t)(q0 + qrow) * p.out_stride + hq * kHD;
+    uint16_t* op = p.out + out_row * p.out_stride + hq * kHD;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -500,19 +557,19 @@ __global__ __launch_bounds__(kPlanThreads) void extend_plan_kernel(const int32_t
     plan_sort_descending(bs * tiles_per_req, key_tiles, plan, bins, part);
 }
 
-template <int NH, int ST>
-static int launch_extend(const ExtendParams& p, int64_t blocks, hipStream_t stream) {
+template <int NH, int ST, bool GROUPED = false>
+static int launch_extend(const ExtendParams& p, int64_t blocks, hipStream_t stream, const GroupedParams& gp = GroupedParams()) {
     constexpr int kLds = ST * kTileBytes;
     static bool configured = false;  // the ring is larger than the 64 KiB a kernel gets by default
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(paged_extend_kernel<NH, ST>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(paged_extend_kernel<NH, ST, GROUPED>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kLds) != hipSuccess) {
             set_error("msgl_paged_extend: cannot reserve %d bytes of LDS", kLds);
             return MSGL_E_LAUNCH;
         }
         configured = true;
     }
-    hipLaunchKernelGGL((paged_extend_kernel<NH, ST>), dim3((unsigned)blocks), dim3(256 * NH), kLds, stream, p);
+    hipLaunchKernelGGL((paged_extend_kernel<NH, ST, GROUPED>), dim3((unsigned)blocks), dim3(256 * NH), kLds, stream, p, gp);
     return check_launch("paged_extend_kernel");
 }
 
@@ -593,4 +650,63 @@ extern "C" int msgl_extend_plan(const int32_t* cu_seqlens_q, const int32_t* pref
     hipLaunchKernelGGL(extend_plan_kernel, dim3(1), dim3(kPlanThreads), 0, static_cast<hipStream_t>(stream), cu_seqlens_q, prefix_lens, bs,
                        (max_seqlen_q + kBM - 1) / kBM, plan);
     return check_launch("extend_plan_kernel");
+}
+
+extern "C" int msgl_shared_prefix_decode(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, int64_t cache_stride,
+                                         const int32_t* req_to_token, int64_t r2t_stride, const int32_t* req_pool_indices,
+                                         const int32_t* seq_lens, const int32_t* start_lens, const int32_t* group_first,
+                                         const int32_t* group_count, const int32_t* group_prefix, int num_groups, int max_members,
+                                         int max_prefix, int key_chunk, void* workspace, size_t workspace_bytes, int bs, int Hq,
+                                         int Hkv, int D, float scale, int max_splits, int chunk_tokens, const int32_t* chunk_dev,
+                                         void* stream) {
+    if (num_groups == 0 || max_members == 0 || max_prefix == 0) return MSGL_OK;
+    MSGL_REQUIRE(num_groups > 0 && max_members > 0 && max_prefix > 0 && bs > 0, "msgl_shared_prefix_decode: groups=%d members=%d prefix=%d bs=%d",
+                 num_groups, max_members, max_prefix, bs);
+    MSGL_REQUIRE(D == kHD, "msgl_shared_prefix_decode: head dim %d unsupported (128 only)", D);
+    MSGL_REQUIRE(Hkv > 0 && Hq > 0 && Hq % Hkv == 0, "msgl_shared_prefix_decode: Hq=%d Hkv=%d", Hq, Hkv);
+    MSGL_REQUIRE(key_chunk > 0 && key_chunk % kBN == 0, "msgl_shared_prefix_decode: key_chunk %d must be a positive multiple of %d", key_chunk, kBN);
+    MSGL_REQUIRE(max_splits >= 2 && max_splits <= 4096, "msgl_shared_prefix_decode: max_splits=%d", max_splits);
+    MSGL_REQUIRE(chunk_dev != nullptr || (chunk_tokens > 0 && chunk_tokens % 16 == 0),
+                 "msgl_shared_prefix_decode: chunk_tokens=%d must be a positive multiple of 16", chunk_tokens);
+    MSGL_REQUIRE(q && k_cache && v_cache && req_to_token && req_pool_indices && seq_lens && start_lens && group_first && group_count &&
+                     group_prefix && workspace,
+                 "msgl_shared_prefix_decode: null pointer argument");
+    MSGL_REQUIRE(aligned16(q) && aligned16(k_cache) && aligned16(v_cache) && aligned16(workspace),
+                 "msgl_shared_prefix_decode: q, k_cache, v_cache and workspace must be 16-byte aligned");
+    MSGL_REQUIRE(q_stride % 8 == 0 && cache_stride % 8 == 0 && cache_stride < (int64_t)1 << 31 && q_stride >= (int64_t)Hq * D &&
+                     cache_stride >= (int64_t)Hkv * D,
+                 "msgl_shared_prefix_decode: bad stride");
+    const size_t need = msgl_paged_decode_workspace_bytes(bs, Hq, D, max_splits);
+    if (workspace_bytes < need) {
+        set_error("msgl_shared_prefix_decode: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+        return MSGL_E_WORKSPACE;
+    }
+    ExtendParams p = {};
+    p.q = static_cast<const uint16_t*>(q);
+    p.q_stride = q_stride;
+    p.kc = static_cast<const uint16_t*>(k_cache);
+    p.vc = static_cast<const uint16_t*>(v_cache);
+    p.cache_stride = (uint32_t)cache_stride;
+    p.r2t = req_to_token;
+    p.r2t_stride = r2t_stride;
+    p.req_idx = req_pool_indices;
+    p.bs = bs;
+    p.hkv = Hkv;
+    p.group = Hq / Hkv;
+    p.scale_log2e = scale * 1.4426950408889634f;
+    GroupedParams g = {};
+    g.first = group_first, g.count = group_count, g.prefix = group_prefix;
+    g.key_chunk = key_chunk;
+    g.key_splits = (max_prefix + key_chunk - 1) / key_chunk;
+    g.row_tiles = (max_members * p.group + kBM - 1) / kBM;
+    g.dec.seq_lens = seq_lens;
+    g.dec.start_lens = start_lens;
+    g.dec.chunk_dev = chunk_dev;
+    g.dec.chunk = chunk_tokens;
+    g.dec.bs = bs, g.dec.Hq = Hq, g.dec.max_splits = max_splits;
+    g.dec.ws_o = static_cast<float*>(workspace);
+    g.dec.ws_ml = g.dec.ws_o + (size_t)bs * max_splits * Hq * D;
+    const int64_t blocks = (int64_t)num_groups * g.row_tiles * g.key_splits * Hkv;
+    MSGL_REQUIRE(blocks <= 0x7fffffff, "msgl_shared_prefix_decode: grid too large");
+    return launch_extend<1, 3, true>(p, blocks, static_cast<hipStream_t>(stream), g);
 }

@@ -96,9 +96,13 @@ def paged_decode(
     kv_stream: bool = True,
     reuse_lens: Optional[torch.Tensor] = None,
     plan: Optional[torch.Tensor] = None,
+    start_lens: Optional[torch.Tensor] = None,
+    extra_splits: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """Decode attention for q [bs, Hq, D] over the paged pool; returns [bs, Hq, D] bf16.
     plan: launch order from decode_plan for the same seq_lens / max_splits / chunk (ragged batches).
+    start_lens / extra_splits: positions below start_lens[b] were handled by shared_prefix_decode, which left
+    extra_splits[b] partial results in the same workspace; they are merged in.
 
     kv_stream: read K/V with the non-temporal hint, except positions below reuse_lens[b] (prefix slots other
     requests share), which stay cacheable.  A pure performance hint."""
@@ -134,6 +138,13 @@ def paged_decode(
     if plan is not None:
         _dev_i32(plan, "plan")
         _need(plan.numel() == bs * max_splits, "plan must have bs * max_splits entries")
+    if extra_splits is not None:
+        _need(start_lens is not None and workspace is not None, "extra_splits needs start_lens and the workspace the partials are in")
+        _dev_i32(extra_splits, "extra_splits")
+        _need(extra_splits.numel() == bs, "extra_splits must have bs entries")
+    if start_lens is not None:
+        _dev_i32(start_lens, "start_lens")
+        _need(start_lens.numel() == bs, "start_lens must have bs entries")
     qs = q.stride(0) if bs > 1 else Hq * D
     os_ = out.stride(0) if bs > 1 else Hq * D
     _check(_lib.msgl_paged_decode(
@@ -145,12 +156,60 @@ def paged_decode(
         bs, Hq, Hkv, D, page_size, float(scale), max_splits, int(chunk_tokens),
         chunk_dev.data_ptr() if chunk_dev is not None else None, 1 if kv_stream else 0,
         reuse_lens.data_ptr() if reuse_lens is not None else None,
-        plan.data_ptr() if plan is not None else None, _stream()))
+        plan.data_ptr() if plan is not None else None,
+        start_lens.data_ptr() if start_lens is not None else None,
+        extra_splits.data_ptr() if extra_splits is not None else None, _stream()))
     return out
 
 
+def shared_prefix_decode(
+    q: torch.Tensor,
+    k_cache: torch.Tensor,
+    v_cache: torch.Tensor,
+    req_to_token: torch.Tensor,
+    req_pool_indices: torch.Tensor,
+    seq_lens: torch.Tensor,
+    start_lens: torch.Tensor,
+    group_first: torch.Tensor,
+    group_count: torch.Tensor,
+    group_prefix: torch.Tensor,
+    max_members: int,
+    max_prefix: int,
+    key_chunk: int,
+    scale: float,
+    workspace: torch.Tensor,
+    max_splits: int,
+    chunk_tokens: int = 0,
+    chunk_dev: Optional[torch.Tensor] = None,
+) -> None:
+    """Attention of every group's decode queries over the group's shared prefix, once per group, left as split
+    partials in `workspace` for the paged_decode call that follows with the same seq_lens / start_lens /
+    max_splits / chunk and extra_splits[b] = ceil(prefix / key_chunk)."""
+    _dev_bf16(q, "q")
+    for t, name in ((req_pool_indices, "req_pool_indices"), (seq_lens, "seq_lens"), (start_lens, "start_lens"),
+                    (group_first, "group_first"), (group_count, "group_count"), (group_prefix, "group_prefix")):
+        _dev_i32(t, name)
+    _need(q.dim() == 3 and q.stride(2) == 1 and q.stride(1) == q.shape[2], "q must be [bs, Hq, D] with dense heads")
+    bs, Hq, D = q.shape
+    Hkv = k_cache.shape[1]
+    cs = _cache_stride(k_cache, v_cache, Hkv, D)
+    ng = group_first.numel()
+    _need(group_count.numel() == ng and group_prefix.numel() == ng, "group arrays must have one entry per group")
+    _need(seq_lens.numel() == bs and start_lens.numel() == bs and req_pool_indices.numel() == bs, "per-request arrays must have bs entries")
+    _need(workspace.is_cuda and workspace.is_contiguous(), "workspace must be a contiguous GPU tensor")
+    if chunk_dev is not None:
+        _dev_i32(chunk_dev, "chunk_dev")
+    _check(_lib.msgl_shared_prefix_decode(
+        q.data_ptr(), q.stride(0) if bs > 1 else Hq * D, k_cache.data_ptr(), v_cache.data_ptr(), cs,
+        req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(), seq_lens.data_ptr(), start_lens.data_ptr(),
+        group_first.data_ptr(), group_count.data_ptr(), group_prefix.data_ptr(), ng, int(max_members), int(max_prefix), int(key_chunk),
+        workspace.data_ptr(), workspace.numel() * workspace.element_size(), bs, Hq, Hkv, D, float(scale), int(max_splits),
+        int(chunk_tokens), chunk_dev.data_ptr() if chunk_dev is not None else None, _stream()))
+
+
 def decode_plan(seq_lens: torch.Tensor, max_splits: int, chunk_tokens: int = 0, chunk_dev: Optional[torch.Tensor] = None,
-                out: Optional[torch.Tensor] = None, sorted_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, sorted_dev: Optional[torch.Tensor] = None,
+                start_lens: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Launch order of paged_decode's (split, request) items for a ragged batch: full splits first, partial tails
     by falling length.  Built on the device from seq_lens; one call per step serves every layer.  sorted_dev: device
     word, 0 = write the identity order instead (decided at run time, for captured graphs)."""
@@ -167,7 +226,8 @@ def decode_plan(seq_lens: torch.Tensor, max_splits: int, chunk_tokens: int = 0, 
         _need(out.numel() == bs * max_splits, "plan must have bs * max_splits entries")
     _check(_lib.msgl_decode_plan(seq_lens.data_ptr(), bs, int(max_splits), int(chunk_tokens),
                                  chunk_dev.data_ptr() if chunk_dev is not None else None,
-                                 sorted_dev.data_ptr() if sorted_dev is not None else None, out.data_ptr(), _stream()))
+                                 sorted_dev.data_ptr() if sorted_dev is not None else None,
+                                 start_lens.data_ptr() if start_lens is not None else None, out.data_ptr(), _stream()))
     return out
 
 

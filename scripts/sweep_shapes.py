@@ -31,7 +31,31 @@ def run(name, Hq, Hkv, ps, seq_lens, groups=None, prefix=None, layers=4, steps=2
     stream = os.environ.get("KV_STREAM", "1") == "1"
     ms_ = max(1, min(ms_, -(-max(seq_lens) // ch)))
     plan = ops.decode_plan(sl, ms_, ch) if (os.environ.get("PLAN", "auto") == "1" or (os.environ.get("PLAN", "auto") == "auto" and max(seq_lens) > 1.25 * sum(seq_lens) / bs)) and ms_ > 1 else None
-    f = lambda i: ops.paged_decode(q, pools[i % layers][0], pools[i % layers][1], r2t, idx, sl, D ** -0.5, ps, out=out, workspace=ws, max_splits=ms_, chunk_tokens=ch,
+    cascade = None
+    if groups is not None and os.environ.get("SHARED", "0") == "1":
+        # shared prefixes once per group through the matrix-core kernel, the rest per request
+        ng = max(groups) + 1
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+        first, count = [groups.index(g) for g in range(ng)], [groups.count(g) for g in range(ng)]
+        kc_ = int(os.environ.get("KEY_CHUNK", "1024"))
+        start = i32([prefix[g] for g in groups])
+        extra = i32([-(-prefix[g] // kc_) for g in groups])
+        rest = [s - prefix[g] for s, g in zip(seq_lens, groups)]
+        ms_ = max_splits or splits_for_batch(bs)
+        ch = chunk or ops.pick_split_planned(rest, ms_ - max(-(-p_ // kc_) for p_ in prefix), Hkv)
+        ms_ = -(-max(rest) // ch) + max(-(-p_ // kc_) for p_ in prefix)
+        ws = torch.empty(max(16, ops.decode_workspace_bytes(bs, Hq, D, ms_)), dtype=torch.uint8, device=dev)
+        plan = ops.decode_plan(sl, ms_, ch, start_lens=start)
+        cascade = (i32(first), i32(count), i32(prefix), max(count), max(prefix), kc_, start, extra)
+    def f(i):
+        kc, vc = pools[i % layers]
+        if cascade is not None:
+            gf, gc, gp, mm, mp, kc_, start, extra = cascade
+            ops.shared_prefix_decode(q, kc, vc, r2t, idx, sl, start, gf, gc, gp, mm, mp, kc_, D ** -0.5, ws, ms_, ch)
+            return ops.paged_decode(q, kc, vc, r2t, idx, sl, D ** -0.5, ps, out=out, workspace=ws, max_splits=ms_, chunk_tokens=ch,
+                                    kv_stream=stream, plan=plan, start_lens=start, extra_splits=extra)
+        return f0(i)
+    f0 = lambda i: ops.paged_decode(q, pools[i % layers][0], pools[i % layers][1], r2t, idx, sl, D ** -0.5, ps, out=out, workspace=ws, max_splits=ms_, chunk_tokens=ch,
                                    kv_stream=stream, reuse_lens=reuse if os.environ.get("REUSE", "1") == "1" else None, plan=plan)
     for i in range(5): f(i)
     torch.cuda.synchronize()
@@ -42,7 +66,7 @@ def run(name, Hq, Hkv, ps, seq_lens, groups=None, prefix=None, layers=4, steps=2
     ms = e0.elapsed_time(e1) / steps
     b = 2 * Hkv * D * 2 * sum(seq_lens)
     ub = 2 * Hkv * D * 2 * pt.unique_tokens
-    print(json.dumps(dict(name=name, bs=bs, Hq=Hq, Hkv=Hkv, ps=ps, tokens=sum(seq_lens), layers=layers, max_splits=ms_, chunk=ch, planned=plan is not None, ms=round(ms, 4),
+    print(json.dumps(dict(name=name, bs=bs, Hq=Hq, Hkv=Hkv, ps=ps, tokens=sum(seq_lens), layers=layers, max_splits=ms_, chunk=ch, planned=plan is not None, cascade=cascade is not None, ms=round(ms, 4),
                           GBps=round(b / ms / 1e6, 1), unique_GBps=round(ub / ms / 1e6, 1))), flush=True)
     del pools
 

@@ -30,13 +30,13 @@ def test_argument_validation_without_gpu():
     from mini_sglang_amd import _capi, ops
 
     lib = _capi.lib
-    rc = lib.msgl_paged_decode(None, 0, None, None, 0, None, 0, None, None, None, 0, None, 0, 1, 16, 8, 96, 1, 1.0, 1, 16, None, 0, None, None, None)
+    rc = lib.msgl_paged_decode(None, 0, None, None, 0, None, 0, None, None, None, 0, None, 0, 1, 16, 8, 96, 1, 1.0, 1, 16, None, 0, None, None, None, None, None)
     assert rc == -1 and "head dim" in _capi.last_error()
-    rc = lib.msgl_paged_decode(None, 0, None, None, 0, None, 0, None, None, None, 0, None, 0, 1, 24, 8, 128, 1, 1.0, 1, 16, None, 0, None, None, None)
+    rc = lib.msgl_paged_decode(None, 0, None, None, 0, None, 0, None, None, None, 0, None, 0, 1, 24, 8, 128, 1, 1.0, 1, 16, None, 0, None, None, None, None, None)
     assert rc == -1 and "null pointer" in _capi.last_error()
     rc = lib.msgl_rmsnorm(None, 0, None, None, 0, 4, 100, 1e-6, None)
     assert rc == -1 and "unsupported" in _capi.last_error()
-    assert lib.msgl_paged_decode(None, 0, None, None, 0, None, 0, None, None, None, 0, None, 0, 0, 16, 8, 128, 1, 1.0, 1, 16, None, 0, None, None, None) == 0
+    assert lib.msgl_paged_decode(None, 0, None, None, 0, None, 0, None, None, None, 0, None, 0, 0, 16, 8, 128, 1, 1.0, 1, 16, None, 0, None, None, None, None, None) == 0
     with pytest.raises(ValueError, match="GPU"):
         ops.rmsnorm(torch.zeros(2, 128, dtype=torch.bfloat16), torch.ones(128, dtype=torch.bfloat16), 1e-6)
     with pytest.raises(ValueError, match="GPU"):

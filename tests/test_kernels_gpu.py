@@ -132,6 +132,53 @@ def test_decode_shared_prefix_rows():
         assert torch.equal(run_decode(case, ps, max_splits=8, chunk_tokens=128, **kw), base)
 
 
+def run_decode_shared(case, page_size, groups, prefix, key_chunk, chunk, max_splits, planned=False):
+    """Shared prefixes once per group (msgl_shared_prefix_decode), the rest per request, one merge."""
+    ops = _ops()
+    kvd = case["kv_full"].to(DEV)
+    kc, vc = kvd[:, 0], kvd[:, 1]
+    bs = len(groups)
+    ng = max(groups) + 1
+    first = [groups.index(g) for g in range(ng)]
+    count = [groups.count(g) for g in range(ng)]
+    assert all(groups[first[g]: first[g] + count[g]] == [g] * count[g] for g in range(ng)), "members must be consecutive"
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    # a group of one has nothing to share: it stays with the per-request kernel
+    gprefix = [prefix[g] if count[g] > 1 else 0 for g in range(ng)]
+    start = i32([gprefix[g] for g in groups])
+    extra = i32([-(-gprefix[g] // key_chunk) for g in groups])
+    q, r2t, idx, sl = case["q"].to(DEV), case["r2t"].to(DEV), case["req_idx"].to(DEV), case["seq_lens"].to(DEV)
+    ws = torch.zeros(ops.decode_workspace_bytes(bs, q.shape[1], 128, max_splits), dtype=torch.uint8, device=DEV)
+    ops.shared_prefix_decode(q, kc, vc, r2t, idx, sl, start, i32(first), i32(count), i32(gprefix), max(count), max(max(gprefix), 1),
+                             key_chunk, 128 ** -0.5, ws, max_splits, chunk)
+    plan = ops.decode_plan(sl, max_splits, chunk, start_lens=start) if planned else None
+    out = ops.paged_decode(q, kc, vc, r2t, idx, sl, 128 ** -0.5, page_size, workspace=ws, max_splits=max_splits, chunk_tokens=chunk,
+                           start_lens=start, extra_splits=extra, plan=plan)
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+@pytest.mark.parametrize("Hq,Hkv,page_size", [(32, 8, 16), (8, 1, 64), (16, 8, 1), (4, 4, 16)])
+def test_decode_shared_prefix_computed_once_per_group(Hq, Hkv, page_size):
+    """Groups of requests whose page-table rows start with the same slots: the shared part goes through the
+    matrix-core kernel once per group, the private part through the gather kernel, and the merged result must match
+    the oracle's per-request attention over the whole row (and the plain decode kernel within rounding).  Covers a
+    group wider than one 128-row tile, a member whose row is nothing but the prefix, a group of one, prefixes that
+    are not multiples of the 64-key tile (page_size 1) and several key slices per prefix."""
+    ps = page_size
+    al = lambda n: -(-n // ps) * ps  # prefixes are page aligned
+    groups = [0] * 3 + [1] * 40 + [2] + [3] * 2
+    prefix = [al(300), al(1000), al(128), al(70)]
+    seq = [prefix[0] + 5, prefix[0], prefix[0] + 700] + [prefix[1] + 1 + 13 * i for i in range(40)] + [500] + [prefix[3] + 1, prefix[3] + 2]
+    case = build_case(Hq, Hkv, ps, seq, seed=71 + Hq, groups=groups, prefix=prefix)
+    base = run_decode(case, ps, max_splits=16, chunk_tokens=256)
+    check_decode(case, base)
+    for key_chunk, planned in [(256, False), (1024, True)]:
+        out = run_decode_shared(case, ps, groups, prefix, key_chunk, chunk=256, max_splits=16, planned=planned)
+        check_decode(case, out)
+        assert (out.float() - base.float()).abs().max().item() <= 2e-2
+
+
 def test_decode_full_size_properties():
     """The headline shape (batch 256 x 8192 tokens, page_size 16, 32 q / 8 kv heads; 8.6 GB of K/V) through
     properties that do not need the CPU oracle for the whole batch: the split size does not change the result

@@ -121,7 +121,7 @@ int main(int argc, char** argv) {
         const int l = i % layers;
         const int rc = msgl_paged_decode(qbuf[l], (int64_t)hq * D, kbuf[l], vbuf[l], cache_stride, d_r2t, max_ctx, d_idx, d_seq,
                                          d_out, (int64_t)hq * D, d_ws, ws_bytes, bs, hq, hkv, D, ps, 0.08838834764831845f,
-                                         splits, chunk, nullptr, kv_stream, nullptr, /*plan=*/nullptr, st);
+                                         splits, chunk, nullptr, kv_stream, nullptr, /*plan=*/nullptr, /*start_lens=*/nullptr, /*extra_splits=*/nullptr, st);
         if (rc != 0) {
             fprintf(stderr, "msgl_paged_decode: %d %s\n", rc, msgl_last_error());
             exit(1);
