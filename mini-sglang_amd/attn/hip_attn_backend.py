@@ -32,6 +32,7 @@ class HipAttnMetadata:
     chunk_dev: Optional[torch.Tensor] = None
     reuse_lens: Optional[torch.Tensor] = None  # per request: leading positions shared with other requests
     decode_plan: Optional[torch.Tensor] = None  # launch order of the (split, request) items (ragged batches)
+    shared: Optional[dict] = None  # groups of requests on one radix prefix, attended once per group (eager decode)
     # extend
     cu_seqlens_q: Optional[torch.Tensor] = None
     max_seqlen_q: int = 0
@@ -59,6 +60,8 @@ class HipAttnBackend(AttentionBackend):
         # K/V rows are read once per step: stream them past the caches (non-temporal), keeping only the
         # prefix positions that several requests share cacheable
         self.kv_stream = True
+        # eager decode steps attend a radix prefix that neighbouring requests share once per run of such requests
+        self.share_prefix_reads = True
         self._planned_split = (None, 0)
         self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count if torch.cuda.is_available() else 256
         self.decode_graph_vars: Optional[dict] = None
@@ -95,6 +98,10 @@ class HipAttnBackend(AttentionBackend):
         bs = batch.seq_lens.numel()
         if batch.forward_mode.is_decode():
             md.max_splits = splits_for_batch(bs)
+            groups = batch.shared_groups() if self.share_prefix_reads and hasattr(batch, "shared_groups") else []
+            if groups:
+                self.forward_metadata = self._shared_prefix_metadata(batch, bs, groups)
+                return
             md.chunk_tokens, ragged = self._decode_split(batch.seq_lens_cpu, bs, md.max_splits)
             # eager launches know the longest sequence: launch only the splits that can be active
             md.max_splits = max(1, min(md.max_splits, -(-int(batch.seq_lens_cpu.max()) // md.chunk_tokens)))
@@ -108,6 +115,31 @@ class HipAttnBackend(AttentionBackend):
             if bs > 1:  # a single request's tiles are already launched longest first
                 md.extend_plan = ops.extend_plan(md.cu_seqlens_q, batch.prefix_seq_lens, md.max_seqlen_q)
         self.forward_metadata = md
+
+    def _shared_prefix_metadata(self, batch, bs: int, groups) -> HipAttnMetadata:
+        """Eager decode of a batch in which runs of requests sit on a common radix prefix: the prefix is attended
+        once per run (ops.shared_prefix_decode), every request's own tail by the gather kernel in planned order,
+        and one merge joins the two.  Not available under graph capture (the group structure is host state)."""
+        i32 = dict(dtype=torch.int32, device=self.device)
+        key_chunk = 1024
+        start, extra = [0] * bs, [0] * bs
+        for first, count, plen in groups:
+            for i in range(first, first + count):
+                start[i], extra[i] = plen, -(-plen // key_chunk)
+        lens = batch.seq_lens_cpu.tolist()
+        rest = [max(1, s - p) for s, p in zip(lens, start)]
+        most_extra = max(extra)
+        own_splits = max(1, splits_for_batch(bs) - most_extra)
+        kv_heads = int(getattr(self.kv_cache_pool, "head_num", 8))
+        chunk = ops.pick_split_planned(rest, own_splits, kv_heads, self._cus)
+        md = HipAttnMetadata(chunk_tokens=chunk, max_splits=-(-max(rest) // chunk) + most_extra)
+        md.reuse_lens = getattr(batch, "shared_prefix_lens", None)
+        md.shared = dict(first=torch.tensor([g[0] for g in groups], **i32), count=torch.tensor([g[1] for g in groups], **i32),
+                         prefix=torch.tensor([g[2] for g in groups], **i32), max_members=max(g[1] for g in groups),
+                         max_prefix=max(g[2] for g in groups), key_chunk=key_chunk,
+                         start=torch.tensor(start, **i32), extra=torch.tensor(extra, **i32))
+        md.decode_plan = ops.decode_plan(batch.seq_lens, md.max_splits, chunk, start_lens=md.shared["start"])
+        return md
 
     # ------------------------------------------------------------------ forward
     def forward_extend(self, q, k, v, layer, batch, save_kv_cache: bool = True):
@@ -128,12 +160,19 @@ class HipAttnBackend(AttentionBackend):
         md = self.forward_metadata
         k_cache, v_cache = self.kv_cache_pool.get_kv_buffer(layer.layer_id)
         bs = q.shape[0]
+        q3 = _as_heads(q, layer.num_heads, layer.head_dim)
+        ws = self._workspace_for(bs, layer.num_heads, layer.head_dim, md.max_splits)
+        sh = md.shared
+        if sh is not None:
+            ops.shared_prefix_decode(q3, k_cache, v_cache, self.req_to_token_pool.req_to_token, batch.req_pool_indices, batch.seq_lens,
+                                     sh["start"], sh["first"], sh["count"], sh["prefix"], sh["max_members"], sh["max_prefix"],
+                                     sh["key_chunk"], layer.scale, ws, md.max_splits, md.chunk_tokens)
         o = ops.paged_decode(
-            _as_heads(q, layer.num_heads, layer.head_dim), k_cache, v_cache, self.req_to_token_pool.req_to_token,
-            batch.req_pool_indices, batch.seq_lens, layer.scale, self.page_size,
-            workspace=self._workspace_for(bs, layer.num_heads, layer.head_dim, md.max_splits),
+            q3, k_cache, v_cache, self.req_to_token_pool.req_to_token,
+            batch.req_pool_indices, batch.seq_lens, layer.scale, self.page_size, workspace=ws,
             max_splits=md.max_splits, chunk_tokens=md.chunk_tokens, chunk_dev=md.chunk_dev,
-            kv_stream=self.kv_stream, reuse_lens=md.reuse_lens, plan=md.decode_plan)
+            kv_stream=self.kv_stream, reuse_lens=md.reuse_lens, plan=md.decode_plan,
+            start_lens=sh["start"] if sh is not None else None, extra_splits=sh["extra"] if sh is not None else None)
         return o.view(bs, layer.num_heads * layer.head_dim)
 
     # ------------------------------------------------------------------ graph hooks

@@ -54,6 +54,9 @@ class Req:
         self.prefix_indices: torch.Tensor = torch.empty(0, dtype=torch.int32)
         self.last_slot: int = -1  # pool slot of the request's last stored token
         self.last_node = None     # radix-cache node that ends the cached prefix (a handle; None = no cache)
+        # identity of the cached prefix the request was prefilled on: (length, first slot, last slot); a slot holds
+        # one token of one radix path, so equal keys mean the same slots at positions [0, length)
+        self.shared_key = None
 
     @property
     def last_token_id(self) -> int:
@@ -147,6 +150,7 @@ class BatchInfo:
         for i, r in enumerate(reqs):
             P, n = prefix_lens[i], extend_lens[i]
             if P:
+                r.shared_key = (P, int(r.prefix_indices[0]), int(r.prefix_indices[P - 1]))
                 row_idx.append(torch.full((P,), rows[i], dtype=torch.int64))
                 col_idx.append(torch.arange(P, dtype=torch.int64))
                 vals.append(r.prefix_indices.to("cpu", torch.int32))
@@ -200,6 +204,19 @@ class BatchInfo:
         self.input_ids = torch.tensor([r.last_token_id for r in reqs], dtype=torch.int32).to(dev)
 
     # ------------------------------------------------------------------ bookkeeping used by callers
+    def shared_groups(self) -> List[tuple]:
+        """Runs of neighbouring requests whose page-table rows start with the same cached prefix, as
+        (first index, count, prefix length); what the attention backend may compute once per run."""
+        groups, i, reqs = [], 0, self.reqs or []
+        while i < len(reqs):
+            j, key = i + 1, reqs[i].shared_key
+            while key is not None and j < len(reqs) and reqs[j].shared_key == key:
+                j += 1
+            if key is not None and j - i >= 2:
+                groups.append((i, j - i, key[0]))
+            i = j
+        return groups
+
     def merge_batch(self, other: "BatchInfo") -> None:
         """batch_info.py:304-317."""
         self.reqs.extend(other.reqs)

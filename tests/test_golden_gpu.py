@@ -228,3 +228,67 @@ def test_radix_cache_hit_generates_the_same_tokens(ps):
     assert warm[0] == cold_a[0] and warm[1] == cold_b[0]
     assert torch.equal(rows[1][: hits[1]], rows[0][: hits[1]]), "the second request reads the first one's slots"
     assert tree.protected_size() == 0 and tree.evictable_size() > 0
+
+
+@pytest.mark.parametrize("ps", [1, 16])
+def test_decode_batch_on_a_shared_radix_prefix(ps):
+    """Three requests prefilled on top of one cached prefix (the radix cache hands all of them the same slots) and
+    decoded as a batch: the backend attends the shared positions once for the run of requests and must produce the
+    tokens it produces when every request reads the prefix for itself."""
+    from mini_sglang_amd.mem_cache import MHAKVPool, PageAllocator, RadixCache, ReqToTokenPool
+    from mini_sglang_amd.runtime import synth
+    from mini_sglang_amd.runtime.batch_info import BatchInfo, Req, SamplingParams
+    from mini_sglang_amd.runtime.model_runner import ModelConfig, ModelRunner, ServerArgs
+    from mini_sglang_amd.runtime.qwen3 import Qwen3Config
+
+    cfg = Qwen3Config(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                      intermediate_size=512, vocab_size=2048, max_position_embeddings=1024, tie_word_embeddings=False)
+    shared = synth.uniform_int(200, 5, 0, 2048).tolist()
+    first = shared + synth.uniform_int(9, 6, 0, 2048).tolist()
+    later = [shared + synth.uniform_int(n, 7 + n, 0, 2048).tolist() for n in (21, 3, 40)]
+    new = 10
+
+    def generate(share):
+        args = ServerArgs(page_size=ps, device=DEV, disable_cuda_graph=True, max_num_reqs=8, random_seed=8, weight_std=0.02,
+                          embed_std=0.3, successor_head=0.04)
+        pages = 2048 // ps
+        r2t = ReqToTokenPool(8, cfg.max_position_embeddings, ps, DEV)
+        pa = PageAllocator(pages, ps)
+        kv = MHAKVPool(pages * ps, ps, torch.bfloat16, cfg.num_key_value_heads, cfg.head_dim, cfg.num_hidden_layers, DEV)
+        mr = ModelRunner(ModelConfig(cfg), args, req_to_token_pool=r2t, page_allocator=pa, kv_cache_pool=kv)
+        mr.attn_backend.share_prefix_reads = share
+        tree = RadixCache(r2t, kv, pa, ps)
+
+        def prefill(prompts, rid0):
+            reqs = []
+            for i, p in enumerate(prompts):
+                req = Req(rid0 + i, p, SamplingParams(0.0))
+                m = tree.match_prefix(req.token_ids[:-1])
+                req.prefix_indices, req.last_node = m.match_indices, m.last_node
+                tree.inc_lock_ref(req.last_node)
+                reqs.append(req)
+            batch = BatchInfo.init_new(reqs, r2t, pa, kv, tree_cache=tree)
+            batch.prepare_for_extend()
+            lg, _ = mr.forward_generate(batch)
+            mr.process_result(batch, lg)
+            for req in reqs:
+                tree.cache_unfinished_req(req)
+            return batch
+
+        prefill([first], 0)
+        batch = prefill(later, 1)
+        groups = batch.shared_groups()
+        used = []
+        for _ in range(new - 1):
+            batch.prepare_for_decode()
+            lg, _ = mr.forward_generate(batch)
+            used.append(mr.attn_backend.forward_metadata.shared is not None)
+            mr.process_result(batch, lg)
+        return [r.token_ids[r.num_prompt_tokens:] for r in batch.reqs], groups, used
+
+    toks_shared, groups, used = generate(True)
+    toks_plain, _, used_plain = generate(False)
+    hit = 200 - 200 % ps if ps > 1 else 200
+    assert groups == [(0, 3, hit)]
+    assert all(used) and not any(used_plain)
+    assert toks_shared == toks_plain and all(len(t) == new for t in toks_shared)
