@@ -268,7 +268,7 @@ def other_decode_configs(args, world, rank):
     D = 128
     out = {}
 
-    def run(name, Hq, Hkv, ps, lens, groups=None, prefix=None, layers=2, steps=12):
+    def run(name, Hq, Hkv, ps, lens, groups=None, prefix=None, layers=2, steps=12, share_once=False):
         bs = len(lens)
         pages = sum(-(-n // ps) for n in lens) + 8
         pt = workload.make_page_table(lens, ps, pages, 3, groups=groups, group_prefix_lens=prefix)
@@ -287,8 +287,31 @@ def other_decode_configs(args, world, rank):
         ws = torch.empty(max(16, ops.decode_workspace_bytes(bs, Hq, D, ms)), dtype=torch.uint8, device=dev)
         reuse = torch.tensor([prefix[g] for g in groups], dtype=torch.int32, device=dev) if groups is not None else None
 
+        cascade = None
+        if groups is not None and share_once:
+            # the backend's eager path for such a batch: every group's prefix once through the matrix-core kernel
+            # (msgl_shared_prefix_decode), the private tails per request, one merge
+            ng = max(groups) + 1
+            i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+            first, count = [groups.index(g) for g in range(ng)], [groups.count(g) for g in range(ng)]
+            key_chunk = 1024
+            start, extra = i32([prefix[g] for g in groups]), i32([-(-prefix[g] // key_chunk) for g in groups])
+            rest = [n - prefix[g] for n, g in zip(lens, groups)]
+            most_extra = max(-(-p_ // key_chunk) for p_ in prefix)
+            chunk = ops.pick_split_planned(rest, splits_for_batch(bs) - most_extra, Hkv)
+            ms = -(-max(rest) // chunk) + most_extra
+            ws = torch.empty(ops.decode_workspace_bytes(bs, Hq, D, ms), dtype=torch.uint8, device=dev)
+            plan = ops.decode_plan(sl, ms, chunk, start_lens=start)
+            cascade = (i32(first), i32(count), i32(prefix), max(count), max(prefix), key_chunk, start, extra)
+
         def f(i):
             kv = pools[i % layers]
+            if cascade is not None:
+                gf, gc, gp, mm, mp, kc, start, extra = cascade
+                ops.shared_prefix_decode(q, kv[:, 0], kv[:, 1], r2t, idx, sl, start, gf, gc, gp, mm, mp, kc, D ** -0.5, ws, ms, chunk)
+                ops.paged_decode(q, kv[:, 0], kv[:, 1], r2t, idx, sl, D ** -0.5, ps, out=o, workspace=ws, max_splits=ms,
+                                 chunk_tokens=chunk, plan=plan, start_lens=start, extra_splits=extra)
+                return
             ops.paged_decode(q, kv[:, 0], kv[:, 1], r2t, idx, sl, D ** -0.5, ps, out=o, workspace=ws, max_splits=ms,
                              chunk_tokens=chunk, reuse_lens=reuse, plan=plan)
 
@@ -312,7 +335,7 @@ def other_decode_configs(args, world, rank):
         b = 2 * Hkv * D * 2
         out[name] = {"GBps_per_gpu": round(b * sum(lens) / t / 1e9, 1), "unique_GBps_per_gpu": round(b * pt.unique_tokens / t / 1e9, 1),
                      "ms_per_launch": round(t * 1e3, 4), "frac_of_hbm_peak": round(b * sum(lens) / t / 1e9 / HBM_PEAK_GBPS, 4),
-                     "chunk_tokens": chunk, "planned_launch": plan is not None}
+                     "chunk_tokens": chunk, "planned_launch": plan is not None, "shared_prefix_once": cascade is not None}
 
     try:
         if world == 1:
@@ -322,6 +345,8 @@ def other_decode_configs(args, world, rank):
         prefix = [1024 * (1 + g % 4) for g in range(16)]
         lens = [max(n, prefix[g] + 16) for n, g in zip(lens, groups)]
         run("qwen3_8b_bs256_mixed_1k_32k_ps16_radix_shared", args.hq // world, args.hkv // world, 16, lens, groups, prefix)
+        run("qwen3_8b_bs256_mixed_1k_32k_ps16_radix_shared_prefix_once", args.hq // world, args.hkv // world, 16, lens, groups, prefix,
+            share_once=True)
     except Exception as e:
         out["error"] = f"{type(e).__name__}: {e}"[:300]
     torch.cuda.empty_cache()
