@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--e2e-ctx", type=int, default=0, help="0 = 8192 if the whole-model KV fits in HBM, else the largest power of two that does")
     ap.add_argument("--e2e-steps", type=int, default=16)
     ap.add_argument("--e2e-eager", action="store_true", help="do not capture decode steps in hipGraphs")
+    ap.add_argument("--allreduce-trial-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -63,6 +64,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.allreduce_trial_child:
+        return allreduce_trial_child(world, rank, local_rank)
     if world > 1:
         import torch.distributed as dist
 
@@ -229,7 +232,7 @@ def main():
         result["extend"] = extend_attention(args, world, rank)
     xgmi_ok = False
     if world > 1 and not args.no_e2e:
-        result["tp_allreduce"] = tp_allreduce_trial(world, rank, barrier)
+        result["tp_allreduce"] = tp_allreduce_trial_isolated(world, rank, local_rank, barrier)
         xgmi_ok = bool(result["tp_allreduce"].get("validated"))
     if not args.no_e2e:
         result["decode_e2e"] = decode_e2e(args, world, rank, barrier)
@@ -455,6 +458,65 @@ def decode_e2e(args, world, rank, barrier):
         return info
     except Exception as e:  # the headline number above must survive a failure here
         return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def allreduce_trial_child(world, rank, local_rank):
+    """One rank of the direct-read all-reduce trial in a process of its own (see tp_allreduce_trial_isolated): a gloo
+    group for the set-up exchange, this rank's GPU, the trial, one line of JSON."""
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    info = tp_allreduce_trial(world, rank, dist.barrier)
+    print("TRIAL " + json.dumps(info), flush=True)
+    dist.destroy_process_group()
+
+
+def tp_allreduce_trial_isolated(world, rank, local_rank, barrier):
+    """The trial below, run by a child process per rank: a kernel that reads peer memory wrongly on this node's
+    links would take its process down, and that must not be the process that owes the benchmark line.  Only
+    when every child reports bit-exact results does the parent use the communicator itself (timing beside RCCL,
+    second decode measurement)."""
+    import subprocess
+
+    import torch.distributed as dist
+
+    info = {"validated": False}
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC")}  # the children rendezvous among themselves
+    env.update(MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    child = None
+    try:
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--allreduce-trial-child"], env=env, capture_output=True,
+                               text=True, timeout=150)
+        lines = [ln for ln in child.stdout.splitlines() if ln.startswith("TRIAL ")]
+        if child.returncode == 0 and lines:
+            info = json.loads(lines[-1][6:])
+        else:
+            info["error"] = f"child exit {child.returncode}: {(child.stderr or child.stdout)[-300:]}"
+    except Exception as e:  # noqa: BLE001 (timeout included: subprocess.run has killed the child)
+        info["error"] = f"{type(e).__name__}: {e}"[:300]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    flag = torch.tensor([1 if info.get("validated") else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    info["validated"] = bool(int(flag[0]))
+    info["isolated"] = True
+    if info["validated"] and "sizes" in info:  # RCCL on the same sizes, in this process
+        for name, entry in info["sizes"].items():
+            x = torch.zeros(int(name.split("x")[0]) * 4096, dtype=torch.bfloat16, device=dev)
+            for _ in range(10):
+                dist.all_reduce(x)
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(100):
+                dist.all_reduce(x)
+            e1.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) * 10.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            entry["rccl_us"] = round(float(t[0]), 2)
+    return info
 
 
 def tp_allreduce_trial(world, rank, barrier):

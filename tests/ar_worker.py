@@ -35,13 +35,6 @@ def main():
     torch.cuda.set_device(dev)
     from mini_sglang_amd.comm import XgmiAllReduce
 
-    if len(sys.argv) > 1 and sys.argv[1] == "bench-trial":  # the validated trial bench.py runs under TP
-        import bench
-
-        info = bench.tp_allreduce_trial(world, rank, dist.barrier)
-        print(f"rank {rank}/{world}: {info}", flush=True)
-        dist.destroy_process_group()
-        sys.exit(0 if info.get("validated") and "sizes" in info else 1)
     comm = XgmiAllReduce(max_bytes=4 << 20)
     sizes = [8, 512, 3 * 4096 + 8, 131072 + 8, 1 << 20]
     bad = []

@@ -45,5 +45,24 @@ def test_allreduce_matches_rank_order_fp32_sum(world):
 
 
 def test_bench_trial_validates_and_times():
-    """The trial bench.py runs before it trusts the direct-read all-reduce for the decode measurement."""
-    _run_ranks(2, "bench-trial")
+    """The trial bench.py runs, one child process per rank, before it trusts the direct-read all-reduce for the
+    decode measurement: here the children themselves, two ranks on this box's GPU."""
+    import json
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               OMP_NUM_THREADS="2")
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    procs = [subprocess.Popen([sys.executable, "-u", bench, "--allreduce-trial-child"], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=150)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+            raise
+        lines = [ln for ln in out.splitlines() if ln.startswith("TRIAL ")]
+        assert p.returncode == 0 and lines, out[-2000:]
+        info = json.loads(lines[-1][6:])
+        assert info["validated"] and set(info["sizes"]) == {"1x4096", "16x4096", "64x4096", "256x4096"}, info
