@@ -236,6 +236,11 @@ def main():
         xgmi_ok = bool(result["tp_allreduce"].get("validated"))
     if not args.no_e2e:
         result["decode_e2e"] = decode_e2e(args, world, rank, barrier)
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        result["decode_e2e_mixed"] = decode_e2e_mixed(args, world, rank, barrier)
         if xgmi_ok:  # the same steps with the o_proj / down_proj / embedding all-reduces on direct peer reads
             from mini_sglang_amd import comm
 
@@ -397,6 +402,45 @@ def extend_attention(args, world, rank):
                 "TFLOPs_per_gpu": round(tf, 1),
                 "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4)}}
     except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def decode_e2e_mixed(args, world, rank, barrier):
+    """Whole-model decode tok/s on the mixed configuration: Qwen3-8B shape, contexts log-uniform in 1k-32k, groups of
+    16 requests on a shared page-aligned 1-4k radix prefix, page_size 16; the largest batch (256, 128, 64 ...) whose
+    K/V fits this GPU's memory beside the weights.  hipGraph replay: the decode kernels run in planned launch order."""
+    from mini_sglang_amd.runtime import decode_loop, workload
+    from mini_sglang_amd.runtime.qwen3 import Qwen3Config
+
+    try:
+        cfg = Qwen3Config.qwen3_8b()
+        ps = 16
+        free, _ = torch.cuda.mem_get_info()
+        per_token = 2 * (cfg.num_key_value_heads // world) * cfg.head_dim * 2 * cfg.num_hidden_layers
+        bs = 256
+        while True:
+            lens = workload.mixed_lengths(bs, 1024, 32768, 3)
+            groups = [i // 16 for i in range(bs)]
+            prefix = [1024 * (1 + g % 4) for g in range(bs // 16)]
+            lens = [max(n, prefix[g] + 16) for n, g in zip(lens, groups)]
+            unique = sum(lens) - sum(15 * p for p in prefix)
+            if (unique + bs * 96) * per_token + 2 * 8.2e9 / world <= 0.8 * free or bs <= 16:
+                break
+            bs //= 2
+        steps = 8
+        mr, batch = decode_loop.build_decode_state(cfg, bs, 0, ps, 2 * steps + 24, use_graph=not args.e2e_eager, seq_lens=lens,
+                                                   groups=groups, group_prefix_lens=prefix)
+        dt = decode_loop.time_decode(mr, batch, steps, 3, barrier=barrier)
+        if world > 1:
+            import torch.distributed as dist
+
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        return {"model": "Qwen3-8B shape, random weights", "batch": bs, "ctx": "log-uniform 1k-32k, 16 requests per shared 1-4k prefix",
+                "tokens_in_context": sum(lens), "page_size": ps, "tp": world, "tok_per_s": round(bs * steps / dt, 1),
+                "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "hip_graph": not args.e2e_eager}
+    except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
