@@ -141,6 +141,12 @@ int msgl_decode_plan(const int32_t* seq_lens, int bs, int max_splits,
  * rows; all int32 device arrays of num_groups entries.  max_members / max_prefix:
  * host-side upper bounds (grid size).  key_chunk: keys per work group, a multiple
  * of 64.
+ * Captured launches (hipGraph) cannot size the grid by the batch: pass items =
+ * num_items int32 work items in device memory (group << 20 | 128-row tile of the
+ * group's members x heads << 14 | key slice; -1 = unused entry; max_members /
+ * max_prefix are then ignored) and, if the slice length changes between replays,
+ * key_chunk_dev (device int32, overrides key_chunk).  The group arrays, start_lens
+ * and the caller's extra_splits are then static buffers refreshed before a replay.
  * ------------------------------------------------------------------------- */
 int msgl_shared_prefix_decode(const void* q, int64_t q_stride,
                               const void* k_cache, const void* v_cache, int64_t cache_stride,
@@ -153,6 +159,7 @@ int msgl_shared_prefix_decode(const void* q, int64_t q_stride,
                               void* workspace, size_t workspace_bytes,
                               int bs, int Hq, int Hkv, int D, float scale,
                               int max_splits, int chunk_tokens, const int32_t* chunk_dev,
+                              const int32_t* items, int num_items, const int32_t* key_chunk_dev,
                               void* stream);
 
 /* ---------------------------------------------------------------------------

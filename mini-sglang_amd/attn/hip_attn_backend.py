@@ -40,6 +40,9 @@ class HipAttnMetadata:
     extend_plan: Optional[torch.Tensor] = None  # launch order of the (request, query tile) items, longest first
 
 
+GRAPH_SHARED_ITEMS = 128  # work items of the shared-prefix kernel in a captured launch (x kv heads work groups)
+
+
 def splits_for_batch(bs: int) -> int:
     """Upper bound on splits per request (the launch has bs * splits work groups, most of which exit at once
     for short requests, at about 2 ns each): up to 4096 groups in all, so a 32k-token request in a batch of 256
@@ -62,6 +65,11 @@ class HipAttnBackend(AttentionBackend):
         self.kv_stream = True
         # eager decode steps attend a radix prefix that neighbouring requests share once per run of such requests
         self.share_prefix_reads = True
+        # ... and captured steps too, if asked for before capture: the captured launch then always contains the
+        # shared-prefix kernel (a few microseconds of idle work groups per layer when no request shares anything)
+        self.share_prefix_in_graphs = False
+        self._graph_groups = []          # runs of requests on a shared prefix in the batch about to be replayed
+        self._graph_shared_key = None    # what the static group buffers currently describe
         self._planned_split = (None, 0)
         self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count if torch.cuda.is_available() else 256
         self.decode_graph_vars: Optional[dict] = None
@@ -164,9 +172,11 @@ class HipAttnBackend(AttentionBackend):
         ws = self._workspace_for(bs, layer.num_heads, layer.head_dim, md.max_splits)
         sh = md.shared
         if sh is not None:
+            self._heads_per_kv_head = layer.num_heads // layer.num_kv_heads
             ops.shared_prefix_decode(q3, k_cache, v_cache, self.req_to_token_pool.req_to_token, batch.req_pool_indices, batch.seq_lens,
                                      sh["start"], sh["first"], sh["count"], sh["prefix"], sh["max_members"], sh["max_prefix"],
-                                     sh["key_chunk"], layer.scale, ws, md.max_splits, md.chunk_tokens)
+                                     sh["key_chunk"], layer.scale, ws, md.max_splits, md.chunk_tokens, chunk_dev=md.chunk_dev,
+                                     items=sh.get("items"), key_chunk_dev=sh.get("key_chunk_dev"))
         o = ops.paged_decode(
             q3, k_cache, v_cache, self.req_to_token_pool.req_to_token,
             batch.req_pool_indices, batch.seq_lens, layer.scale, self.page_size, workspace=ws,
@@ -186,6 +196,12 @@ class HipAttnBackend(AttentionBackend):
                                   # next refresh sorts it (ragged batch) or writes the identity (uniform batch)
                                   "plan": torch.arange(most_items, dtype=torch.int32, device=self.device),
                                   "plan_sorted": torch.zeros(1, dtype=torch.int32, device=self.device)}
+        if self.share_prefix_in_graphs:
+            z = lambda n, v=0: torch.full((n,), v, dtype=torch.int32, device=self.device)
+            # group arrays, per-request start / extra-split counts, the shared-prefix kernel's work list and slice length
+            self.decode_graph_vars.update(sh_first=z(max_bs), sh_count=z(max_bs), sh_prefix=z(max_bs), sh_start=z(max_bs),
+                                          sh_extra=z(max_bs), sh_items=z(GRAPH_SHARED_ITEMS, -1), sh_key_chunk=z(1, 1024))
+        self._graph_shared_key = None
         self.decode_graph_metadata = {}
         if num_heads is None:
             num_heads = getattr(self, "graph_num_heads", None)
@@ -202,6 +218,11 @@ class HipAttnBackend(AttentionBackend):
                              decode_plan=self.decode_graph_vars["plan"][: bs * splits] if splits > 1 else None)
         if md.decode_plan is not None:  # valid for any lengths until the first refresh
             md.decode_plan.copy_(torch.arange(bs * splits, dtype=torch.int32, device=self.device))
+        if self.share_prefix_in_graphs and bs >= 2 and splits >= 2:
+            v = self.decode_graph_vars
+            md.shared = dict(first=v["sh_first"], count=v["sh_count"], prefix=v["sh_prefix"], start=v["sh_start"][:bs],
+                             extra=v["sh_extra"][:bs], items=v["sh_items"], key_chunk_dev=v["sh_key_chunk"], key_chunk=1024,
+                             max_members=0, max_prefix=0)
         self.decode_graph_metadata[bs] = md
         self.forward_metadata = md
 
@@ -212,8 +233,15 @@ class HipAttnBackend(AttentionBackend):
         copies a [bs, max_ctx] table every step)."""
         md = self.decode_graph_metadata[bs]
         if forward_mode.is_decode():
+            own_splits = md.max_splits
+            if md.shared is not None:
+                most_extra, start = self._refresh_graph_shared(bs, md)
+                own_splits -= most_extra
+                if most_extra:  # the gather kernel reads what lies behind the shared prefixes
+                    n = seq_lens_cpu.numel()  # the unpadded batch
+                    seq_lens_cpu = (seq_lens_cpu - torch.tensor(start[:n], dtype=seq_lens_cpu.dtype)).clamp_(min=1)
             # padded rows have length 1; they only lower the average, never the maximum
-            chunk, ragged = self._decode_split(seq_lens_cpu, bs, md.max_splits)
+            chunk, ragged = self._decode_split(seq_lens_cpu, bs, own_splits)
             self.decode_graph_vars["chunk"].fill_(chunk)
             self.decode_graph_vars["plan_sorted"].fill_(1 if ragged else 0)
             self.refresh_decode_plan(bs, seq_lens)
@@ -226,7 +254,47 @@ class HipAttnBackend(AttentionBackend):
         md = self.decode_graph_metadata[bs]
         if md.decode_plan is not None:
             ops.decode_plan(seq_lens[:bs], md.max_splits, chunk_dev=md.chunk_dev, out=md.decode_plan,
-                            sorted_dev=self.decode_graph_vars["plan_sorted"])
+                            sorted_dev=self.decode_graph_vars["plan_sorted"],
+                            start_lens=md.shared["start"] if md.shared is not None else None)
+
+    def set_graph_shared_groups(self, groups) -> None:
+        """Optional, before a replay: the batch's runs of requests on a shared radix prefix, [(first, count, prefix
+        length)] (BatchInfo.shared_groups()).  Like set_graph_reuse_lens, not part of the reference's hook set."""
+        self._graph_groups = list(groups or [])
+
+    def _refresh_graph_shared(self, bs: int, md: HipAttnMetadata):
+        """Bring the static group buffers in line with the groups announced for this replay.  Returns (largest number
+        of prefix slices of any group, per-request start positions).  Groups are dropped as a whole when their work
+        list or their slices do not fit what was captured."""
+        v = self.decode_graph_vars
+        groups = [g for g in self._graph_groups if g[0] + g[1] <= bs] if self.share_prefix_reads else []
+        heads = getattr(self, "_heads_per_kv_head", 4)
+        key_chunk, items = 1024, None
+        while groups:
+            items = ops.shared_prefix_items(groups, heads, key_chunk, GRAPH_SHARED_ITEMS)
+            if items is not None and max(-(-g[2] // key_chunk) for g in groups) <= md.max_splits - 1:
+                break
+            key_chunk *= 2
+            if key_chunk > 65536:
+                groups, items = [], None
+        start, extra = [0] * bs, [0] * bs
+        for first, count, plen in groups:
+            for i in range(first, first + count):
+                start[i], extra[i] = plen, -(-plen // key_chunk)
+        key = (bs, tuple(groups), key_chunk)
+        if key != self._graph_shared_key:
+            i32 = dict(dtype=torch.int32)
+            pad = lambda vals, n: torch.tensor(list(vals) + [0] * (n - len(vals)), **i32)
+            n = v["sh_first"].numel()
+            v["sh_first"].copy_(pad([g[0] for g in groups], n))
+            v["sh_count"].copy_(pad([g[1] for g in groups], n))
+            v["sh_prefix"].copy_(pad([g[2] for g in groups], n))
+            v["sh_start"].copy_(pad(start, v["sh_start"].numel()))
+            v["sh_extra"].copy_(pad(extra, v["sh_extra"].numel()))
+            v["sh_items"].copy_(torch.tensor(items if groups else [-1] * GRAPH_SHARED_ITEMS, **i32))
+            v["sh_key_chunk"].fill_(key_chunk)
+            self._graph_shared_key = key
+        return max(extra) if groups else 0, start
 
     def set_graph_reuse_lens(self, shared_prefix_lens: Optional[torch.Tensor]) -> None:
         """Optional, before a replay: per-request shared-prefix lengths for the cache-policy hint (None = none).

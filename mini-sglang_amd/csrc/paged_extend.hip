@@ -74,6 +74,10 @@ struct GroupedParams {
     int key_chunk;          // keys per work group (a multiple of 64)
     int key_splits;         // ceil(longest prefix / key_chunk)
     int row_tiles;          // ceil(most members * heads per kv head / 128)
+    // Captured launches: the grid cannot follow the group structure, so the host lists the work items
+    // (group << 20 | row tile << 14 | key slice; -1 = none) and the slice length in device memory.
+    const int32_t* items;
+    const int32_t* key_chunk_dev;
     DecodeParams dec;       // seq_lens, start_lens, split size, max_splits, Hq, workspace of the decode launch
 };
 
@@ -172,13 +176,21 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
     if constexpr (GROUPED) {
         int idx = blockIdx.x;
         hk = idx % p.hkv, idx /= p.hkv;
-        g_split = idx % gp.key_splits, idx /= gp.key_splits;
-        const int rt = idx % gp.row_tiles;
-        const int gi = idx / gp.row_tiles;
+        int rt, gi;
+        if (gp.items) {
+            const int item = gp.items[idx];
+            if (item < 0) return;
+            gi = item >> 20, rt = (item >> 14) & 63, g_split = item & 0x3fff;
+        } else {
+            g_split = idx % gp.key_splits, idx /= gp.key_splits;
+            rt = idx % gp.row_tiles;
+            gi = idx / gp.row_tiles;
+        }
+        const int key_chunk = gp.key_chunk_dev ? *gp.key_chunk_dev : gp.key_chunk;
         const int first = gp.first[gi], rows = gp.count[gi] * p.group, pre = gp.prefix[gi];
-        const int key0 = g_split * gp.key_chunk;
+        const int key0 = g_split * key_chunk;
         if (rt * kBM >= rows || key0 >= pre) return;
-        kv_len = min(pre - key0, gp.key_chunk);  // positions are counted from key0
+        kv_len = min(pre - key0, key_chunk);  // positions are counted from key0
         nkt = (kv_len + kBN - 1) / kBN;
         const int row0 = rt * kBM + (wave & 3) * 32;
         const int row = row0 + n;
@@ -658,13 +670,16 @@ extern "C" int msgl_shared_prefix_decode(const void* q, int64_t q_stride, const 
                                          const int32_t* group_count, const int32_t* group_prefix, int num_groups, int max_members,
                                          int max_prefix, int key_chunk, void* workspace, size_t workspace_bytes, int bs, int Hq,
                                          int Hkv, int D, float scale, int max_splits, int chunk_tokens, const int32_t* chunk_dev,
-                                         void* stream) {
-    if (num_groups == 0 || max_members == 0 || max_prefix == 0) return MSGL_OK;
-    MSGL_REQUIRE(num_groups > 0 && max_members > 0 && max_prefix > 0 && bs > 0, "msgl_shared_prefix_decode: groups=%d members=%d prefix=%d bs=%d",
-                 num_groups, max_members, max_prefix, bs);
+                                         const int32_t* items, int num_items, const int32_t* key_chunk_dev, void* stream) {
+    if (items == nullptr && (num_groups == 0 || max_members == 0 || max_prefix == 0)) return MSGL_OK;
+    if (items != nullptr && num_items == 0) return MSGL_OK;
+    MSGL_REQUIRE(bs > 0 && (items != nullptr ? num_items > 0 && num_items <= 65536
+                                             : (num_groups > 0 && num_groups < 2048 && max_members > 0 && max_prefix > 0)),
+                 "msgl_shared_prefix_decode: groups=%d members=%d prefix=%d items=%d bs=%d", num_groups, max_members, max_prefix, num_items, bs);
     MSGL_REQUIRE(D == kHD, "msgl_shared_prefix_decode: head dim %d unsupported (128 only)", D);
     MSGL_REQUIRE(Hkv > 0 && Hq > 0 && Hq % Hkv == 0, "msgl_shared_prefix_decode: Hq=%d Hkv=%d", Hq, Hkv);
-    MSGL_REQUIRE(key_chunk > 0 && key_chunk % kBN == 0, "msgl_shared_prefix_decode: key_chunk %d must be a positive multiple of %d", key_chunk, kBN);
+    MSGL_REQUIRE(key_chunk_dev != nullptr || (key_chunk > 0 && key_chunk % kBN == 0),
+                 "msgl_shared_prefix_decode: key_chunk %d must be a positive multiple of %d", key_chunk, kBN);
     MSGL_REQUIRE(max_splits >= 2 && max_splits <= 4096, "msgl_shared_prefix_decode: max_splits=%d", max_splits);
     MSGL_REQUIRE(chunk_dev != nullptr || (chunk_tokens > 0 && chunk_tokens % 16 == 0),
                  "msgl_shared_prefix_decode: chunk_tokens=%d must be a positive multiple of 16", chunk_tokens);
@@ -697,8 +712,10 @@ extern "C" int msgl_shared_prefix_decode(const void* q, int64_t q_stride, const 
     GroupedParams g = {};
     g.first = group_first, g.count = group_count, g.prefix = group_prefix;
     g.key_chunk = key_chunk;
-    g.key_splits = (max_prefix + key_chunk - 1) / key_chunk;
-    g.row_tiles = (max_members * p.group + kBM - 1) / kBM;
+    g.key_chunk_dev = key_chunk_dev;
+    g.items = items;
+    g.key_splits = items ? 1 : (max_prefix + key_chunk - 1) / key_chunk;
+    g.row_tiles = items ? 1 : (max_members * p.group + kBM - 1) / kBM;
     g.dec.seq_lens = seq_lens;
     g.dec.start_lens = start_lens;
     g.dec.chunk_dev = chunk_dev;
@@ -706,7 +723,7 @@ extern "C" int msgl_shared_prefix_decode(const void* q, int64_t q_stride, const 
     g.dec.bs = bs, g.dec.Hq = Hq, g.dec.max_splits = max_splits;
     g.dec.ws_o = static_cast<float*>(workspace);
     g.dec.ws_ml = g.dec.ws_o + (size_t)bs * max_splits * Hq * D;
-    const int64_t blocks = (int64_t)num_groups * g.row_tiles * g.key_splits * Hkv;
+    const int64_t blocks = (items ? (int64_t)num_items : (int64_t)num_groups * g.row_tiles * g.key_splits) * Hkv;
     MSGL_REQUIRE(blocks <= 0x7fffffff, "msgl_shared_prefix_decode: grid too large");
     return launch_extend<1, 3, true>(p, blocks, static_cast<hipStream_t>(stream), g);
 }

@@ -21,7 +21,7 @@ from . import synth, workload
 
 def build_decode_state(cfg: Qwen3Config, bs: int, ctx: int, page_size: int, steps_budget: int, *, device="cuda",
                        use_graph: bool = True, seed: int = 0, groups=None, group_prefix_lens=None, seq_lens=None,
-                       kv_layout: str = "interleaved", max_ctx: Optional[int] = None):
+                       kv_layout: str = "interleaved", max_ctx: Optional[int] = None, share_prefix_in_graphs: bool = False):
     rank, tp = _tp()
     ps = page_size
     seq_lens = list(seq_lens) if seq_lens is not None else [ctx] * bs
@@ -36,7 +36,8 @@ def build_decode_state(cfg: Qwen3Config, bs: int, ctx: int, page_size: int, step
     cfg.max_position_embeddings = max(max_ctx, 2048)
     args = ServerArgs(page_size=ps, device=device, disable_cuda_graph=not use_graph, max_num_reqs=bs, max_capture_bs=bs,
                       random_seed=seed, num_kv_tokens=pool_pages * ps, kv_layout=kv_layout, weight_std=0.01, embed_std=0.3,
-                      successor_head=0.02 if not cfg.tie_word_embeddings else 0.0)
+                      successor_head=0.02 if not cfg.tie_word_embeddings else 0.0,
+                      share_prefix_in_graphs=share_prefix_in_graphs)
     mr = ModelRunner(ModelConfig(cfg), args, gpu_id=torch.cuda.current_device() if device != "cpu" else 0, tp_rank=rank, tp_size=tp)
     # contexts live in pages 1..ctx_pages (drawn in a seeded random order, the same table on every rank); the
     # allocator keeps pages ctx_pages+1.. for the tokens the decode steps append
@@ -58,6 +59,9 @@ def build_decode_state(cfg: Qwen3Config, bs: int, ctx: int, page_size: int, step
         r.token_ids = [0] * (S - 1) + r.token_ids  # only the length and the last token matter for decode
         r.req_pool_idx = rows[i]
         r.last_slot = int(pt.req_to_token[i, S - 1])
+        if groups is not None and group_prefix_lens[groups[i]] > 0:  # as prepare_for_extend records a radix-cache hit
+            P = group_prefix_lens[groups[i]]
+            r.shared_key = (P, int(pt.req_to_token[i, 0]), int(pt.req_to_token[i, P - 1]))
         reqs.append(r)
     batch = BatchInfo.init_new(reqs, mr.req_to_token_pool, mr.page_allocator, mr.kv_cache_pool)
     batch.forward_mode = ForwardMode.DECODE

@@ -80,6 +80,8 @@ class DeviceDecodeLoop:
         """The split size is the only launch parameter that depends on the lengths; sized for the longest
         request after `steps` more tokens."""
         grown = self.seq_lens_cpu + steps
+        if hasattr(self.mr.attn_backend, "set_graph_shared_groups"):
+            self.mr.attn_backend.set_graph_shared_groups(self.batch.shared_groups())
         self.mr.attn_backend.init_forward_metadata_replay_cuda_graph(
             self.bs, req_pool_indices=self.req_pool_indices, seq_lens=self.seq_lens, seq_lens_cpu=grown,
             forward_mode=ForwardMode.DECODE)

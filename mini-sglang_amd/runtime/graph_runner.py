@@ -86,6 +86,8 @@ class HipGraphRunner:
         self.req_pool_indices[:raw].copy_(batch.req_pool_indices)
         if hasattr(self.mr.attn_backend, "set_graph_reuse_lens"):
             self.mr.attn_backend.set_graph_reuse_lens(batch.shared_prefix_lens)
+        if hasattr(self.mr.attn_backend, "set_graph_shared_groups"):
+            self.mr.attn_backend.set_graph_shared_groups(batch.shared_groups())
         self.mr.attn_backend.init_forward_metadata_replay_cuda_graph(
             bs, req_pool_indices=self.req_pool_indices, seq_lens=self.seq_lens, seq_lens_cpu=batch.seq_lens_cpu,
             forward_mode=batch.forward_mode)

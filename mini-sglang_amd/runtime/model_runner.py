@@ -33,6 +33,7 @@ class ServerArgs:
     weight_std: float = 0.02
     embed_std: Optional[float] = None
     successor_head: float = 0.0     # see runtime.qwen3.init_weights
+    share_prefix_in_graphs: bool = False  # captured decode steps attend shared radix prefixes once per group of requests
 
 
 @dataclasses.dataclass
@@ -95,6 +96,7 @@ class ModelRunner:
             from ..attn.hip_attn_backend import HipAttnBackend
             self.attn_backend = HipAttnBackend(self)
             self.attn_backend.graph_num_heads = self.model_config.num_heads // self.tp_size
+            self.attn_backend.share_prefix_in_graphs = bool(self.server_args.share_prefix_in_graphs)
         else:
             raise ValueError(f"Unsupported attention backend: {self.server_args.attention_backend}")
 

@@ -230,11 +230,13 @@ def test_radix_cache_hit_generates_the_same_tokens(ps):
     assert tree.protected_size() == 0 and tree.evictable_size() > 0
 
 
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
 @pytest.mark.parametrize("ps", [1, 16])
-def test_decode_batch_on_a_shared_radix_prefix(ps):
+def test_decode_batch_on_a_shared_radix_prefix(ps, graph):
     """Three requests prefilled on top of one cached prefix (the radix cache hands all of them the same slots) and
     decoded as a batch: the backend attends the shared positions once for the run of requests and must produce the
-    tokens it produces when every request reads the prefix for itself."""
+    tokens it produces when every request reads the prefix for itself.  Eagerly, and replayed from a captured graph
+    whose static group buffers the replay hook fills (padded batch: 3 requests in the graph of 4)."""
     from mini_sglang_amd.mem_cache import MHAKVPool, PageAllocator, RadixCache, ReqToTokenPool
     from mini_sglang_amd.runtime import synth
     from mini_sglang_amd.runtime.batch_info import BatchInfo, Req, SamplingParams
@@ -249,8 +251,8 @@ def test_decode_batch_on_a_shared_radix_prefix(ps):
     new = 10
 
     def generate(share):
-        args = ServerArgs(page_size=ps, device=DEV, disable_cuda_graph=True, max_num_reqs=8, random_seed=8, weight_std=0.02,
-                          embed_std=0.3, successor_head=0.04)
+        args = ServerArgs(page_size=ps, device=DEV, disable_cuda_graph=not graph, max_num_reqs=8, max_capture_bs=4, random_seed=8,
+                          weight_std=0.02, embed_std=0.3, successor_head=0.04, share_prefix_in_graphs=graph)
         pages = 2048 // ps
         r2t = ReqToTokenPool(8, cfg.max_position_embeddings, ps, DEV)
         pa = PageAllocator(pages, ps)
@@ -281,8 +283,10 @@ def test_decode_batch_on_a_shared_radix_prefix(ps):
         used = []
         for _ in range(new - 1):
             batch.prepare_for_decode()
-            lg, _ = mr.forward_generate(batch)
-            used.append(mr.attn_backend.forward_metadata.shared is not None)
+            lg, replayed = mr.forward_generate(batch)
+            assert replayed == graph
+            be = mr.attn_backend
+            used.append(bool(be._graph_shared_key[1]) if graph else be.forward_metadata.shared is not None)
             mr.process_result(batch, lg)
         return [r.token_ids[r.num_prompt_tokens:] for r in batch.reqs], groups, used
 
@@ -292,3 +296,42 @@ def test_decode_batch_on_a_shared_radix_prefix(ps):
     assert groups == [(0, 3, hit)]
     assert all(used) and not any(used_plain)
     assert toks_shared == toks_plain and all(len(t) == new for t in toks_shared)
+
+
+def test_chained_and_replayed_steps_on_shared_prefixes():
+    """A decode batch with two runs of requests on shared prefixes (512 and 16 tokens): per-request reads (eager),
+    shared reads (eager), host-prepared graph replays and device-chained steps with shared reads all generate
+    the same tokens."""
+    from mini_sglang_amd.runtime import decode_loop
+    from mini_sglang_amd.runtime.device_decode import DeviceDecodeLoop
+    from mini_sglang_amd.runtime.qwen3 import Qwen3Config
+
+    ps, steps = 16, 12
+    lens, groups, prefix = [700, 650, 900, 300, 20], [0, 0, 0, 1, 1], [512, 16]
+
+    def build(use_graph, share):
+        torch.manual_seed(4321)
+        cfg = Qwen3Config(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                          intermediate_size=512, vocab_size=2048, max_position_embeddings=4096, tie_word_embeddings=False)
+        mr, batch = decode_loop.build_decode_state(cfg, 5, 0, ps, 64, use_graph=use_graph, seed=3, seq_lens=list(lens), groups=groups,
+                                                   group_prefix_lens=prefix, share_prefix_in_graphs=use_graph and share)
+        mr.attn_backend.share_prefix_reads = share
+        return mr, batch
+
+    def tokens(batch):
+        return [r.token_ids[-steps:] for r in batch.reqs]
+
+    mr, plain = build(False, False)
+    decode_loop.decode_steps(mr, plain, steps)
+    mr, shared = build(False, True)
+    assert shared.shared_groups() == [(0, 3, 512), (3, 2, 16)]
+    decode_loop.decode_steps(mr, shared, steps)
+    assert mr.attn_backend.forward_metadata.shared is not None
+    mr, replayed = build(True, True)
+    decode_loop.decode_steps(mr, replayed, steps)
+    assert mr.attn_backend._graph_shared_key[1] == ((0, 3, 512), (3, 2, 16))
+    mr, chained = build(True, True)
+    loop = DeviceDecodeLoop(mr, chained, max_steps=16)
+    loop.run(steps)
+    loop.sync_host()
+    assert tokens(plain) == tokens(shared) == tokens(replayed) == tokens(chained)
