@@ -428,18 +428,28 @@ def decode_e2e_mixed(args, world, rank, barrier):
                 break
             bs //= 2
         steps = 8
-        mr, batch = decode_loop.build_decode_state(cfg, bs, 0, ps, 2 * steps + 24, use_graph=not args.e2e_eager, seq_lens=lens,
-                                                   groups=groups, group_prefix_lens=prefix)
-        dt = decode_loop.time_decode(mr, batch, steps, 3, barrier=barrier)
-        if world > 1:
-            import torch.distributed as dist
+        info = {"model": "Qwen3-8B shape, random weights", "batch": bs, "ctx": "log-uniform 1k-32k, 16 requests per shared 1-4k prefix",
+                "tokens_in_context": sum(lens), "page_size": ps, "tp": world, "steps": steps, "hip_graph": not args.e2e_eager}
+        # every request reads its prefix itself, then: each group's prefix attended once per step (msgl_shared_prefix_decode)
+        for suffix, share in (("", False), ("_prefix_once", True)):
+            import gc
 
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t[0])
-        return {"model": "Qwen3-8B shape, random weights", "batch": bs, "ctx": "log-uniform 1k-32k, 16 requests per shared 1-4k prefix",
-                "tokens_in_context": sum(lens), "page_size": ps, "tp": world, "tok_per_s": round(bs * steps / dt, 1),
-                "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "hip_graph": not args.e2e_eager}
+            mr, batch = decode_loop.build_decode_state(cfg, bs, 0, ps, 2 * steps + 24, use_graph=not args.e2e_eager, seq_lens=lens,
+                                                       groups=groups, group_prefix_lens=prefix, share_prefix_in_graphs=share)
+            mr.attn_backend.share_prefix_reads = share
+            dt = decode_loop.time_decode(mr, batch, steps, 3, barrier=barrier)
+            if world > 1:
+                import torch.distributed as dist
+
+                t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t[0])
+            info["tok_per_s" + suffix] = round(bs * steps / dt, 1)
+            info["ms_per_step" + suffix] = round(dt / steps * 1e3, 3)
+            del mr, batch
+            gc.collect()
+            torch.cuda.empty_cache()
+        return info
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
