@@ -416,6 +416,12 @@ def decode_e2e_mixed(args, world, rank, barrier):
         cfg = Qwen3Config.qwen3_8b()
         ps = 16
         free, _ = torch.cuda.mem_get_info()
+        if world > 1:  # every rank must build the same batch: size it for the rank with the least free memory
+            import torch.distributed as dist
+
+            f = torch.tensor([free], dtype=torch.int64, device="cuda")
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            free = int(f[0])
         per_token = 2 * (cfg.num_key_value_heads // world) * cfg.head_dim * 2 * cfg.num_hidden_layers
         bs = 256
         while True:
