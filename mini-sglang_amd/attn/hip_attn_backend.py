@@ -40,7 +40,7 @@ class HipAttnMetadata:
     extend_plan: Optional[torch.Tensor] = None  # launch order of the (request, query tile) items, longest first
 
 
-GRAPH_SHARED_ITEMS = 128  # work items of the shared-prefix kernel in a captured launch (x kv heads work groups)
+GRAPH_SHARED_ITEMS = 32  # work items of the shared-prefix kernel in a captured launch (x kv heads work groups, one round of the chip when idle)
 
 
 def splits_for_batch(bs: int) -> int:
