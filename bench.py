@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Headline benchmark: paged decode attention on MI355X, Qwen3-8B geometry, page_size 16, batch 256,
-8192-token contexts (the configuration BASELINE.json's metric is quoted on).
+8192-token contexts (the configuration the headline metric is quoted on).
 
 A "step" is one decode-attention call (one transformer layer's worth: new K/V already in the pool, one
 query token per request attends to its whole paged context).  Steps cycle over several layers' pools so

@@ -188,7 +188,7 @@ E2E_CASES = {
                       vocab_size=2048, max_position_embeddings=1024, tie_word_embeddings=True), 1, (41, [5, 19]), 64, 7, 0.05, 0.05, 0.0),
     "tiny_ps16": (dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, intermediate_size=512,
                        vocab_size=2048, max_position_embeddings=1024, tie_word_embeddings=False), 16, (42, [15, 16, 33]), 64, 8, 0.02, 0.3, 0.04),
-    # BASELINE config 1: Qwen3-0.6B shape, page_size 1, 256 greedy tokens, batch 2 (about 6 minutes of host time)
+    # first configuration of the benchmark family: Qwen3-0.6B shape, page_size 1, 256 greedy tokens, batch 2 (about 6 minutes of host time)
     "qwen3_0.6b_ps1": (dict(max_position_embeddings=2048, tie_word_embeddings=False), 1, (43, [16, 29]), 256, 11, 0.01, 0.3, 0.02),
 }
 

@@ -1,4 +1,4 @@
-"""Decode-attention bandwidth over the BASELINE configurations (kernel level, one layer per launch)."""
+"""Decode-attention bandwidth over the benchmark family's configurations (kernel level, one layer per launch)."""
 import json, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -91,7 +91,7 @@ def _check_e2e(got, fx, need_identical_stream):
 
 @pytest.mark.parametrize("name,strict", [("tiny_ps1", False), ("tiny_ps16", True), ("qwen3_0.6b_ps1", True)])
 def test_e2e_greedy_stream_vs_reference_fixture(name, strict):
-    """BASELINE config 1 ("qwen3_0.6b_ps1": Qwen3-0.6B shape, page_size 1, 256 greedy tokens) and two small
+    """First configuration of the benchmark family ("qwen3_0.6b_ps1": Qwen3-0.6B shape, page_size 1, 256 greedy tokens) and two small
     cases: HIP attention backend + HIP layers reproduce the reference's token stream, logits within 2e-2."""
     fx = gc.load(f"e2e_{name}.pt")
     got = gc.run_e2e(name, DEV, kv_layout="interleaved")
