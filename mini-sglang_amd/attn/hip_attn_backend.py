@@ -11,7 +11,11 @@ Differences from the FA3 backend that matter to a caller:
     graph-replay hook only refreshes the split size in a 4-byte device word;
   * page ids are never read from ``req_to_page`` (its writer is wrong for multi-page prefixes,
     mini_sglang/mem_cache/req2token.py:86-91); ``req_to_token`` is the only table used;
-  * q may be a row-strided view of the qkv GEMM output (no ``.contiguous()`` copy).
+  * q may be a row-strided view of the qkv GEMM output (no ``.contiguous()`` copy);
+  * scheduling metadata is built on the device once per forward and shared by all layers: the launch order of
+    ragged decode and extend batches (longest work item first), and, for decode batches in which neighbouring
+    requests sit on one radix prefix (``batch.shared_groups()``), the group arrays that let that prefix be
+    attended once per group instead of once per request.
 """
 from __future__ import annotations
 
@@ -32,7 +36,7 @@ class HipAttnMetadata:
     chunk_dev: Optional[torch.Tensor] = None
     reuse_lens: Optional[torch.Tensor] = None  # per request: leading positions shared with other requests
     decode_plan: Optional[torch.Tensor] = None  # launch order of the (split, request) items (ragged batches)
-    shared: Optional[dict] = None  # groups of requests on one radix prefix, attended once per group (eager decode)
+    shared: Optional[dict] = None  # groups of requests on one radix prefix, attended once per group
     # extend
     cu_seqlens_q: Optional[torch.Tensor] = None
     max_seqlen_q: int = 0
@@ -40,7 +44,8 @@ class HipAttnMetadata:
     extend_plan: Optional[torch.Tensor] = None  # launch order of the (request, query tile) items, longest first
 
 
-GRAPH_SHARED_ITEMS = 32  # work items of the shared-prefix kernel in a captured launch (x kv heads work groups, one round of the chip when idle)
+# work items of the shared-prefix kernel in a captured launch (times the kv heads = work groups; one round of the chip when idle)
+GRAPH_SHARED_ITEMS = 32
 
 
 def splits_for_batch(bs: int) -> int:
@@ -127,7 +132,7 @@ class HipAttnBackend(AttentionBackend):
     def _shared_prefix_metadata(self, batch, bs: int, groups) -> HipAttnMetadata:
         """Eager decode of a batch in which runs of requests sit on a common radix prefix: the prefix is attended
         once per run (ops.shared_prefix_decode), every request's own tail by the gather kernel in planned order,
-        and one merge joins the two.  Not available under graph capture (the group structure is host state)."""
+        and one merge joins the two.  (Captured steps: _refresh_graph_shared.)"""
         i32 = dict(dtype=torch.int32, device=self.device)
         key_chunk = 1024
         start, extra = [0] * bs, [0] * bs
