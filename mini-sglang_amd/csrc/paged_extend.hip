@@ -525,6 +525,7 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
         // split partial of (member, head): slot = the member's own split count + this key slice
         const DecodeParams& dp = gp.dec;
         const SplitInfo si = split_info(dp, g_member, split_chunk(dp));
+        if (si.nsplit + g_split >= dp.max_splits) return;  // caller error (no room for this slice): stay inside the member's slots
         const int64_t row = ((int64_t)g_member * dp.max_splits + si.nsplit + g_split) * dp.Hq + hq;
         float* po = dp.ws_o + row * kHD;
 #pragma unroll
