@@ -70,11 +70,14 @@ class HipAttnBackend(AttentionBackend):
         self.kv_stream = True
         # eager decode steps attend a radix prefix that neighbouring requests share once per run of such requests
         self.share_prefix_reads = True
-        # ... and captured steps too, if asked for before capture: the captured launch then always contains the
-        # shared-prefix kernel (a few microseconds of idle work groups per layer when no request shares anything)
-        self.share_prefix_in_graphs = False
+        # ... and captured steps too: a runner captures a second graph per batch size that contains the shared-prefix
+        # kernel (capture_shared_prefix = True while it does) and replays it for batches that announce such runs
+        self.share_prefix_in_graphs = True
+        self.capture_shared_prefix = False
         self._graph_groups = []          # runs of requests on a shared prefix in the batch about to be replayed
+        self._graph_use_shared = False   # ... and whether that batch replays the graph with the shared-prefix kernel
         self._graph_shared_key = None    # what the static group buffers currently describe
+        self.decode_graph_metadata_shared: Dict[int, HipAttnMetadata] = {}
         self._planned_split = (None, 0)
         self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count if torch.cuda.is_available() else 256
         self.decode_graph_vars: Optional[dict] = None
@@ -201,13 +204,13 @@ class HipAttnBackend(AttentionBackend):
                                   # next refresh sorts it (ragged batch) or writes the identity (uniform batch)
                                   "plan": torch.arange(most_items, dtype=torch.int32, device=self.device),
                                   "plan_sorted": torch.zeros(1, dtype=torch.int32, device=self.device)}
-        if self.share_prefix_in_graphs:
-            z = lambda n, v=0: torch.full((n,), v, dtype=torch.int32, device=self.device)
-            # group arrays, per-request start / extra-split counts, the shared-prefix kernel's work list and slice length
-            self.decode_graph_vars.update(sh_first=z(max_bs), sh_count=z(max_bs), sh_prefix=z(max_bs), sh_start=z(max_bs),
-                                          sh_extra=z(max_bs), sh_items=z(GRAPH_SHARED_ITEMS, -1), sh_key_chunk=z(1, 1024))
+        z = lambda n, v=0: torch.full((n,), v, dtype=torch.int32, device=self.device)
+        # group arrays, per-request start / extra-split counts, the shared-prefix kernel's work list and slice length
+        self.decode_graph_vars.update(sh_first=z(max_bs), sh_count=z(max_bs), sh_prefix=z(max_bs), sh_start=z(max_bs),
+                                      sh_extra=z(max_bs), sh_items=z(GRAPH_SHARED_ITEMS, -1), sh_key_chunk=z(1, 1024))
         self._graph_shared_key = None
         self.decode_graph_metadata = {}
+        self.decode_graph_metadata_shared = {}
         if num_heads is None:
             num_heads = getattr(self, "graph_num_heads", None)
         if num_heads is not None:
@@ -223,20 +226,30 @@ class HipAttnBackend(AttentionBackend):
                              decode_plan=self.decode_graph_vars["plan"][: bs * splits] if splits > 1 else None)
         if md.decode_plan is not None:  # valid for any lengths until the first refresh
             md.decode_plan.copy_(torch.arange(bs * splits, dtype=torch.int32, device=self.device))
-        if self.share_prefix_in_graphs and bs >= 2 and splits >= 2:
+        if self.capture_shared_prefix:
+            assert self.graph_can_share_prefix(bs), "no room for shared-prefix partials at this batch size"
             v = self.decode_graph_vars
             md.shared = dict(first=v["sh_first"], count=v["sh_count"], prefix=v["sh_prefix"], start=v["sh_start"][:bs],
                              extra=v["sh_extra"][:bs], items=v["sh_items"], key_chunk_dev=v["sh_key_chunk"], key_chunk=1024,
                              max_members=0, max_prefix=0)
-        self.decode_graph_metadata[bs] = md
+            self.reset_graph_shared()  # the capture's warm-up runs see a batch in which nothing is shared
+            self.decode_graph_metadata_shared[bs] = md
+        else:
+            self.decode_graph_metadata[bs] = md
         self.forward_metadata = md
+
+    def graph_can_share_prefix(self, bs: int) -> bool:
+        return self.share_prefix_in_graphs and bs >= 2 and splits_for_batch(bs) >= 2
+
+    def _graph_md(self, bs: int) -> HipAttnMetadata:
+        return (self.decode_graph_metadata_shared if self._graph_use_shared else self.decode_graph_metadata)[bs]
 
     def init_forward_metadata_replay_cuda_graph(self, bs: int, req_pool_indices: torch.Tensor, seq_lens: torch.Tensor,
                                                 seq_lens_cpu: torch.Tensor, forward_mode):
         """The kernels read req_pool_indices / seq_lens from the runner's static buffers; only the split size
         depends on the batch, and it lives in one device word (compare fa3_attn_backend.py:203-233, which
         copies a [bs, max_ctx] table every step)."""
-        md = self.decode_graph_metadata[bs]
+        md = self._graph_md(bs)
         if forward_mode.is_decode():
             own_splits = md.max_splits
             if md.shared is not None:
@@ -256,16 +269,29 @@ class HipAttnBackend(AttentionBackend):
         """Rewrite the static launch order from the lengths now in `seq_lens` (device).  The replay hook calls it;
         a runner whose captured step changes the lengths itself (device-side batch preparation) calls it once more
         inside the step, after the lengths are final."""
-        md = self.decode_graph_metadata[bs]
+        md = self._graph_md(bs)
         if md.decode_plan is not None:
             ops.decode_plan(seq_lens[:bs], md.max_splits, chunk_dev=md.chunk_dev, out=md.decode_plan,
                             sorted_dev=self.decode_graph_vars["plan_sorted"],
                             start_lens=md.shared["start"] if md.shared is not None else None)
 
-    def set_graph_shared_groups(self, groups) -> None:
+    def set_graph_shared_groups(self, groups, bs: int) -> bool:
         """Optional, before a replay: the batch's runs of requests on a shared radix prefix, [(first, count, prefix
-        length)] (BatchInfo.shared_groups()).  Like set_graph_reuse_lens, not part of the reference's hook set."""
+        length)] (BatchInfo.shared_groups()), and the batch size of the graph it will run in.  Returns whether the
+        replay should use the graph that was captured with the shared-prefix kernel (capture_shared_prefix) — the
+        replay hook then refreshes that graph's static state.  Like set_graph_reuse_lens, not part of the
+        reference's hook set; a runner that never calls it gets per-request prefix reads."""
         self._graph_groups = list(groups or [])
+        self._graph_use_shared = bool(self._graph_groups) and self.share_prefix_reads and self.graph_can_share_prefix(bs)
+        return self._graph_use_shared
+
+    def reset_graph_shared(self) -> None:
+        """Static group buffers back to "nothing is shared"."""
+        v = self.decode_graph_vars
+        for name in ("sh_first", "sh_count", "sh_prefix", "sh_start", "sh_extra"):
+            v[name].zero_()
+        v["sh_items"].fill_(-1)
+        self._graph_shared_key = None
 
     def _refresh_graph_shared(self, bs: int, md: HipAttnMetadata):
         """Bring the static group buffers in line with the groups announced for this replay.  Returns (largest number

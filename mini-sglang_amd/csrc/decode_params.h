@@ -51,7 +51,7 @@ __device__ __forceinline__ SplitInfo split_info(const DecodeParams& p, int b, in
     r.S = p.seq_lens[b];
     r.start = p.start_lens ? p.start_lens[b] : 0;
     r.extra = p.extra_splits ? p.extra_splits[b] : 0;
-    r.nsplit = min((r.S - r.start + chunk - 1) / chunk, p.max_splits);
+    r.nsplit = max(0, min((r.S - r.start + chunk - 1) / chunk, p.max_splits));
     return r;
 }
 

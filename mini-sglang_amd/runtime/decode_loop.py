@@ -21,7 +21,7 @@ from . import synth, workload
 
 def build_decode_state(cfg: Qwen3Config, bs: int, ctx: int, page_size: int, steps_budget: int, *, device="cuda",
                        use_graph: bool = True, seed: int = 0, groups=None, group_prefix_lens=None, seq_lens=None,
-                       kv_layout: str = "interleaved", max_ctx: Optional[int] = None, share_prefix_in_graphs: bool = False):
+                       kv_layout: str = "interleaved", max_ctx: Optional[int] = None, share_prefix_in_graphs: bool = True):
     rank, tp = _tp()
     ps = page_size
     seq_lens = list(seq_lens) if seq_lens is not None else [ctx] * bs

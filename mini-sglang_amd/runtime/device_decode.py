@@ -50,9 +50,17 @@ class DeviceDecodeLoop:
             out_cache_loc=self.out_cache_loc, req_pool_indices=self.req_pool_indices, req_to_token_pool=mr.req_to_token_pool,
             kv_cache_pool=mr.kv_cache_pool, page_allocator=mr.page_allocator, attn_backend=mr.attn_backend, reqs=[], device=dev)
         be = mr.attn_backend
-        if getattr(be, "decode_graph_vars", None) is None or bs not in getattr(be, "decode_graph_metadata", {}):
+        if getattr(be, "decode_graph_vars", None) is None:
             be.init_cuda_graph_state(max(bs, getattr(mr.graph_runner, "max_bs", 0) if mr.graph_runner else 0))
-            be.init_forward_metadata_capture_cuda_graph(bs, ForwardMode.DECODE)
+        # runs of requests on a shared radix prefix: this loop's graph then contains the backend's shared-prefix kernel
+        self.shared = hasattr(be, "set_graph_shared_groups") and be.set_graph_shared_groups(batch.shared_groups(), bs)
+        have = getattr(be, "decode_graph_metadata_shared" if self.shared else "decode_graph_metadata", {})
+        if bs not in have:
+            be.capture_shared_prefix = self.shared
+            try:
+                be.init_forward_metadata_capture_cuda_graph(bs, ForwardMode.DECODE)
+            finally:
+                be.capture_shared_prefix = False
         self.graph = None
         self._capture()
 
@@ -81,7 +89,7 @@ class DeviceDecodeLoop:
         request after `steps` more tokens."""
         grown = self.seq_lens_cpu + steps
         if hasattr(self.mr.attn_backend, "set_graph_shared_groups"):
-            self.mr.attn_backend.set_graph_shared_groups(self.batch.shared_groups())
+            self.mr.attn_backend.set_graph_shared_groups(self.batch.shared_groups() if self.shared else [], self.bs)
         self.mr.attn_backend.init_forward_metadata_replay_cuda_graph(
             self.bs, req_pool_indices=self.req_pool_indices, seq_lens=self.seq_lens, seq_lens_cpu=grown,
             forward_mode=ForwardMode.DECODE)

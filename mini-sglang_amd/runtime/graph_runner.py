@@ -38,8 +38,11 @@ class HipGraphRunner:
         self.out_cache_loc = torch.zeros(self.max_bs, dtype=torch.int32, device=dev)
         self.seq_lens = torch.ones(self.max_bs, dtype=torch.int32, device=dev)
         self.req_pool_indices = torch.zeros(self.max_bs, dtype=torch.int32, device=dev)
+        # keyed by batch size; a second set, captured on first use, also contains the backend's shared-prefix kernel
         self.graphs: Dict[int, torch.cuda.CUDAGraph] = {}
         self.outputs: Dict[int, torch.Tensor] = {}
+        self.graphs_shared: Dict[int, torch.cuda.CUDAGraph] = {}
+        self.outputs_shared: Dict[int, torch.Tensor] = {}
         self.pool = None
         self.mr.attn_backend.init_cuda_graph_state(self.max_bs)
         with torch.inference_mode():
@@ -54,9 +57,19 @@ class HipGraphRunner:
                          kv_cache_pool=mr.kv_cache_pool, page_allocator=mr.page_allocator, attn_backend=mr.attn_backend,
                          reqs=[], device=mr.device)
 
-    def _capture(self, bs: int) -> None:
+    @torch.inference_mode()
+    def _capture(self, bs: int, shared_prefix: bool = False) -> None:
         batch = self._static_batch(bs)
-        self.mr.attn_backend.init_forward_metadata_capture_cuda_graph(bs, batch.forward_mode)
+        be = self.mr.attn_backend
+        if shared_prefix:  # captured in the middle of serving: the static inputs go back to a harmless batch first
+            self.input_ids.zero_(), self.positions.zero_(), self.out_cache_loc.zero_(), self.req_pool_indices.zero_()
+            self.seq_lens.fill_(1)
+            be.capture_shared_prefix = True
+        try:
+            be.init_forward_metadata_capture_cuda_graph(bs, batch.forward_mode)
+        finally:
+            if shared_prefix:
+                be.capture_shared_prefix = False
         for _ in range(2):  # warm-up outside capture (library handles, lazy init)
             torch.cuda.synchronize()
             self.mr.model(batch.input_ids, batch.positions, batch)
@@ -65,8 +78,8 @@ class HipGraphRunner:
         with torch.cuda.graph(g, pool=self.pool):
             out = self.mr.model(batch.input_ids, batch.positions, batch)
         self.pool = g.pool()
-        self.graphs[bs] = g
-        self.outputs[bs] = out
+        (self.graphs_shared if shared_prefix else self.graphs)[bs] = g
+        (self.outputs_shared if shared_prefix else self.outputs)[bs] = out
         torch.cuda.synchronize()
 
     def can_run(self, batch: BatchInfo) -> bool:
@@ -79,6 +92,11 @@ class HipGraphRunner:
             self.seq_lens.fill_(1)
             self.out_cache_loc.zero_()
             self.req_pool_indices.zero_()
+        be = self.mr.attn_backend
+        shared = hasattr(be, "set_graph_shared_groups") and be.set_graph_shared_groups(batch.shared_groups(), bs)
+        if shared and bs not in self.graphs_shared:
+            self._capture(bs, shared_prefix=True)
+            be.set_graph_shared_groups(batch.shared_groups(), bs)
         self.input_ids[:raw].copy_(batch.input_ids)
         self.positions[:raw].copy_(batch.positions)
         self.seq_lens[:raw].copy_(batch.seq_lens)
@@ -86,10 +104,8 @@ class HipGraphRunner:
         self.req_pool_indices[:raw].copy_(batch.req_pool_indices)
         if hasattr(self.mr.attn_backend, "set_graph_reuse_lens"):
             self.mr.attn_backend.set_graph_reuse_lens(batch.shared_prefix_lens)
-        if hasattr(self.mr.attn_backend, "set_graph_shared_groups"):
-            self.mr.attn_backend.set_graph_shared_groups(batch.shared_groups())
         self.mr.attn_backend.init_forward_metadata_replay_cuda_graph(
             bs, req_pool_indices=self.req_pool_indices, seq_lens=self.seq_lens, seq_lens_cpu=batch.seq_lens_cpu,
             forward_mode=batch.forward_mode)
-        self.graphs[bs].replay()
-        return self.outputs[bs][:raw]
+        (self.graphs_shared if shared else self.graphs)[bs].replay()
+        return (self.outputs_shared if shared else self.outputs)[bs][:raw]

@@ -33,7 +33,7 @@ class ServerArgs:
     weight_std: float = 0.02
     embed_std: Optional[float] = None
     successor_head: float = 0.0     # see runtime.qwen3.init_weights
-    share_prefix_in_graphs: bool = False  # captured decode steps attend shared radix prefixes once per group of requests
+    share_prefix_in_graphs: bool = True   # captured decode steps attend shared radix prefixes once per group of requests
 
 
 @dataclasses.dataclass

@@ -252,7 +252,7 @@ def test_decode_batch_on_a_shared_radix_prefix(ps, graph):
 
     def generate(share):
         args = ServerArgs(page_size=ps, device=DEV, disable_cuda_graph=not graph, max_num_reqs=8, max_capture_bs=4, random_seed=8,
-                          weight_std=0.02, embed_std=0.3, successor_head=0.04, share_prefix_in_graphs=graph)
+                          weight_std=0.02, embed_std=0.3, successor_head=0.04)
         pages = 2048 // ps
         r2t = ReqToTokenPool(8, cfg.max_position_embeddings, ps, DEV)
         pa = PageAllocator(pages, ps)
@@ -286,7 +286,7 @@ def test_decode_batch_on_a_shared_radix_prefix(ps, graph):
             lg, replayed = mr.forward_generate(batch)
             assert replayed == graph
             be = mr.attn_backend
-            used.append(bool(be._graph_shared_key[1]) if graph else be.forward_metadata.shared is not None)
+            used.append(bool(be._graph_use_shared and be._graph_shared_key[1]) if graph else be.forward_metadata.shared is not None)
             mr.process_result(batch, lg)
         return [r.token_ids[r.num_prompt_tokens:] for r in batch.reqs], groups, used
 
@@ -314,7 +314,7 @@ def test_chained_and_replayed_steps_on_shared_prefixes():
         cfg = Qwen3Config(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
                           intermediate_size=512, vocab_size=2048, max_position_embeddings=4096, tie_word_embeddings=False)
         mr, batch = decode_loop.build_decode_state(cfg, 5, 0, ps, 64, use_graph=use_graph, seed=3, seq_lens=list(lens), groups=groups,
-                                                   group_prefix_lens=prefix, share_prefix_in_graphs=use_graph and share)
+                                                   group_prefix_lens=prefix)
         mr.attn_backend.share_prefix_reads = share
         return mr, batch
 
