@@ -136,9 +136,10 @@ int msgl_decode_plan(const int32_t* seq_lens, int bs, int max_splits,
  * no group) and extra_splits[b] = ceil(prefix / key_chunk), skips those positions
  * and merges these partials with its own.  The reference has no counterpart: its
  * backends read a shared prefix once per request.
- * Group g = requests group_first[g] .. group_first[g] + group_count[g] - 1 of the
- * batch (consecutive), sharing positions [0, group_prefix[g]) of their req_to_token
- * rows; all int32 device arrays of num_groups entries.  max_members / max_prefix:
+ * Group g has group_count[g] members sharing positions [0, group_prefix[g]) of their
+ * req_to_token rows (int32 device arrays of num_groups entries).  Its members are the
+ * batch entries group_members[group_first[g] + i], i < group_count[g], or, with
+ * group_members == NULL, the consecutive entries group_first[g] + i.  max_members / max_prefix:
  * host-side upper bounds (grid size).  key_chunk: keys per work group, a multiple
  * of 64.
  * Captured launches (hipGraph) cannot size the grid by the batch: pass items =
@@ -154,7 +155,8 @@ int msgl_shared_prefix_decode(const void* q, int64_t q_stride,
                               const int32_t* req_pool_indices,
                               const int32_t* seq_lens, const int32_t* start_lens,
                               const int32_t* group_first, const int32_t* group_count,
-                              const int32_t* group_prefix, int num_groups,
+                              const int32_t* group_prefix, const int32_t* group_members,
+                              int num_groups,
                               int max_members, int max_prefix, int key_chunk,
                               void* workspace, size_t workspace_bytes,
                               int bs, int Hq, int Hkv, int D, float scale,

@@ -139,8 +139,8 @@ class HipAttnBackend(AttentionBackend):
         i32 = dict(dtype=torch.int32, device=self.device)
         key_chunk = 1024
         start, extra = [0] * bs, [0] * bs
-        for first, count, plen in groups:
-            for i in range(first, first + count):
+        for members, plen in groups:
+            for i in members:
                 start[i], extra[i] = plen, -(-plen // key_chunk)
         lens = batch.seq_lens_cpu.tolist()
         rest = [max(1, s - p) for s, p in zip(lens, start)]
@@ -150,9 +150,10 @@ class HipAttnBackend(AttentionBackend):
         chunk = ops.pick_split_planned(rest, own_splits, kv_heads, self._cus)
         md = HipAttnMetadata(chunk_tokens=chunk, max_splits=-(-max(rest) // chunk) + most_extra)
         md.reuse_lens = getattr(batch, "shared_prefix_lens", None)
-        md.shared = dict(first=torch.tensor([g[0] for g in groups], **i32), count=torch.tensor([g[1] for g in groups], **i32),
-                         prefix=torch.tensor([g[2] for g in groups], **i32), max_members=max(g[1] for g in groups),
-                         max_prefix=max(g[2] for g in groups), key_chunk=key_chunk,
+        first, flat = _flatten_groups(groups)
+        md.shared = dict(first=torch.tensor(first, **i32), count=torch.tensor([len(g[0]) for g in groups], **i32),
+                         prefix=torch.tensor([g[1] for g in groups], **i32), members=torch.tensor(flat, **i32),
+                         max_members=max(len(g[0]) for g in groups), max_prefix=max(g[1] for g in groups), key_chunk=key_chunk,
                          start=torch.tensor(start, **i32), extra=torch.tensor(extra, **i32))
         md.decode_plan = ops.decode_plan(batch.seq_lens, md.max_splits, chunk, start_lens=md.shared["start"])
         return md
@@ -184,7 +185,7 @@ class HipAttnBackend(AttentionBackend):
             ops.shared_prefix_decode(q3, k_cache, v_cache, self.req_to_token_pool.req_to_token, batch.req_pool_indices, batch.seq_lens,
                                      sh["start"], sh["first"], sh["count"], sh["prefix"], sh["max_members"], sh["max_prefix"],
                                      sh["key_chunk"], layer.scale, ws, md.max_splits, md.chunk_tokens, chunk_dev=md.chunk_dev,
-                                     items=sh.get("items"), key_chunk_dev=sh.get("key_chunk_dev"))
+                                     items=sh.get("items"), key_chunk_dev=sh.get("key_chunk_dev"), group_members=sh["members"])
         o = ops.paged_decode(
             q3, k_cache, v_cache, self.req_to_token_pool.req_to_token,
             batch.req_pool_indices, batch.seq_lens, layer.scale, self.page_size, workspace=ws,
@@ -206,7 +207,7 @@ class HipAttnBackend(AttentionBackend):
                                   "plan_sorted": torch.zeros(1, dtype=torch.int32, device=self.device)}
         z = lambda n, v=0: torch.full((n,), v, dtype=torch.int32, device=self.device)
         # group arrays, per-request start / extra-split counts, the shared-prefix kernel's work list and slice length
-        self.decode_graph_vars.update(sh_first=z(max_bs), sh_count=z(max_bs), sh_prefix=z(max_bs), sh_start=z(max_bs),
+        self.decode_graph_vars.update(sh_first=z(max_bs), sh_count=z(max_bs), sh_prefix=z(max_bs), sh_members=z(max_bs), sh_start=z(max_bs),
                                       sh_extra=z(max_bs), sh_items=z(GRAPH_SHARED_ITEMS, -1), sh_key_chunk=z(1, 1024))
         self._graph_shared_key = None
         self.decode_graph_metadata = {}
@@ -229,7 +230,7 @@ class HipAttnBackend(AttentionBackend):
         if self.capture_shared_prefix:
             assert self.graph_can_share_prefix(bs), "no room for shared-prefix partials at this batch size"
             v = self.decode_graph_vars
-            md.shared = dict(first=v["sh_first"], count=v["sh_count"], prefix=v["sh_prefix"], start=v["sh_start"][:bs],
+            md.shared = dict(first=v["sh_first"], count=v["sh_count"], prefix=v["sh_prefix"], members=v["sh_members"], start=v["sh_start"][:bs],
                              extra=v["sh_extra"][:bs], items=v["sh_items"], key_chunk_dev=v["sh_key_chunk"], key_chunk=1024,
                              max_members=0, max_prefix=0)
             self.reset_graph_shared()  # the capture's warm-up runs see a batch in which nothing is shared
@@ -276,7 +277,7 @@ class HipAttnBackend(AttentionBackend):
                             start_lens=md.shared["start"] if md.shared is not None else None)
 
     def set_graph_shared_groups(self, groups, bs: int) -> bool:
-        """Optional, before a replay: the batch's runs of requests on a shared radix prefix, [(first, count, prefix
+        """Optional, before a replay: the batch's groups of requests on a shared radix prefix, [(member indices, prefix
         length)] (BatchInfo.shared_groups()), and the batch size of the graph it will run in.  Returns whether the
         replay should use the graph that was captured with the shared-prefix kernel (capture_shared_prefix) — the
         replay hook then refreshes that graph's static state.  Like set_graph_reuse_lens, not part of the
@@ -288,7 +289,7 @@ class HipAttnBackend(AttentionBackend):
     def reset_graph_shared(self) -> None:
         """Static group buffers back to "nothing is shared"."""
         v = self.decode_graph_vars
-        for name in ("sh_first", "sh_count", "sh_prefix", "sh_start", "sh_extra"):
+        for name in ("sh_first", "sh_count", "sh_prefix", "sh_members", "sh_start", "sh_extra"):
             v[name].zero_()
         v["sh_items"].fill_(-1)
         self._graph_shared_key = None
@@ -298,28 +299,30 @@ class HipAttnBackend(AttentionBackend):
         of prefix slices of any group, per-request start positions).  Groups are dropped as a whole when their work
         list or their slices do not fit what was captured."""
         v = self.decode_graph_vars
-        groups = [g for g in self._graph_groups if g[0] + g[1] <= bs] if self.share_prefix_reads else []
+        groups = [g for g in self._graph_groups if max(g[0]) < bs] if self.share_prefix_reads else []
         heads = getattr(self, "_heads_per_kv_head", 4)
         key_chunk, items = 1024, None
         while groups:
             items = ops.shared_prefix_items(groups, heads, key_chunk, GRAPH_SHARED_ITEMS)
-            if items is not None and max(-(-g[2] // key_chunk) for g in groups) <= md.max_splits - 1:
+            if items is not None and max(-(-g[1] // key_chunk) for g in groups) <= md.max_splits - 1:
                 break
             key_chunk *= 2
             if key_chunk > 65536:
                 groups, items = [], None
         start, extra = [0] * bs, [0] * bs
-        for first, count, plen in groups:
-            for i in range(first, first + count):
+        for members, plen in groups:
+            for i in members:
                 start[i], extra[i] = plen, -(-plen // key_chunk)
         key = (bs, tuple(groups), key_chunk)
         if key != self._graph_shared_key:
             i32 = dict(dtype=torch.int32)
             pad = lambda vals, n: torch.tensor(list(vals) + [0] * (n - len(vals)), **i32)
             n = v["sh_first"].numel()
-            v["sh_first"].copy_(pad([g[0] for g in groups], n))
-            v["sh_count"].copy_(pad([g[1] for g in groups], n))
-            v["sh_prefix"].copy_(pad([g[2] for g in groups], n))
+            first, flat = _flatten_groups(groups)
+            v["sh_first"].copy_(pad(first, n))
+            v["sh_count"].copy_(pad([len(g[0]) for g in groups], n))
+            v["sh_prefix"].copy_(pad([g[1] for g in groups], n))
+            v["sh_members"].copy_(pad(flat, n))
             v["sh_start"].copy_(pad(start, v["sh_start"].numel()))
             v["sh_extra"].copy_(pad(extra, v["sh_extra"].numel()))
             v["sh_items"].copy_(torch.tensor(items if groups else [-1] * GRAPH_SHARED_ITEMS, **i32))
@@ -334,6 +337,15 @@ class HipAttnBackend(AttentionBackend):
         buf.zero_()
         if shared_prefix_lens is not None:
             buf[: shared_prefix_lens.numel()].copy_(shared_prefix_lens)
+
+
+def _flatten_groups(groups):
+    """[(member indices, prefix length)] -> (offset of every group in the flat member list, the flat list)."""
+    first, flat = [], []
+    for members, _ in groups:
+        first.append(len(flat))
+        flat.extend(members)
+    return first, flat
 
 
 def _as_heads(q: torch.Tensor, num_heads: int, head_dim: int) -> torch.Tensor:

@@ -68,8 +68,9 @@ struct ExtendParams {
 // visible to every row.  The result is not an output row but a split partial (unnormalised O, running max, sum)
 // in the decode workspace, in the slots behind the request's own splits, for the decode merge kernel.
 struct GroupedParams {
-    const int32_t* first;   // per group: index of its first request in the batch (members are consecutive)
+    const int32_t* first;   // per group: index of its first member (in the batch, or in `members` when that is given)
     const int32_t* count;   // per group: number of member requests
+    const int32_t* members; // optional: batch indices of the members, group after group; NULL = members are consecutive
     const int32_t* prefix;  // per group: shared prefix length in tokens
     int key_chunk;          // keys per work group (a multiple of 64)
     int key_splits;         // ceil(longest prefix / key_chunk)
@@ -195,12 +196,13 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
         const int row0 = rt * kBM + (wave & 3) * 32;
         const int row = row0 + n;
         qvalid = row < rows;
-        g_member = first + (qvalid ? row / p.group : 0);
+        const int member0 = gp.members ? gp.members[first] : first;
+        g_member = qvalid ? (gp.members ? gp.members[first + row / p.group] : first + row / p.group) : member0;
         hq = hk * p.group + (qvalid ? row % p.group : 0);
         qpos = kv_len - 1;  // no causal structure: every row sees the whole slice
         full_nkt = kv_len / kBN;
         my_nkt = row0 < rows ? nkt : 0;
-        r2t_row = p.r2t + (int64_t)p.req_idx[first] * p.r2t_stride + key0;
+        r2t_row = p.r2t + (int64_t)p.req_idx[member0] * p.r2t_stride + key0;
         qp = p.q + (int64_t)g_member * p.q_stride + hq * kHD + h * 8;
     } else {
 
@@ -668,7 +670,8 @@ extern "C" int msgl_extend_plan(const int32_t* cu_seqlens_q, const int32_t* pref
 extern "C" int msgl_shared_prefix_decode(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, int64_t cache_stride,
                                          const int32_t* req_to_token, int64_t r2t_stride, const int32_t* req_pool_indices,
                                          const int32_t* seq_lens, const int32_t* start_lens, const int32_t* group_first,
-                                         const int32_t* group_count, const int32_t* group_prefix, int num_groups, int max_members,
+                                         const int32_t* group_count, const int32_t* group_prefix, const int32_t* group_members,
+                                         int num_groups, int max_members,
                                          int max_prefix, int key_chunk, void* workspace, size_t workspace_bytes, int bs, int Hq,
                                          int Hkv, int D, float scale, int max_splits, int chunk_tokens, const int32_t* chunk_dev,
                                          const int32_t* items, int num_items, const int32_t* key_chunk_dev, void* stream) {
@@ -711,7 +714,7 @@ extern "C" int msgl_shared_prefix_decode(const void* q, int64_t q_stride, const 
     p.group = Hq / Hkv;
     p.scale_log2e = scale * 1.4426950408889634f;
     GroupedParams g = {};
-    g.first = group_first, g.count = group_count, g.prefix = group_prefix;
+    g.first = group_first, g.count = group_count, g.prefix = group_prefix, g.members = group_members;
     g.key_chunk = key_chunk;
     g.key_chunk_dev = key_chunk_dev;
     g.items = items;

@@ -183,11 +183,14 @@ def shared_prefix_decode(
     chunk_dev: Optional[torch.Tensor] = None,
     items: Optional[torch.Tensor] = None,
     key_chunk_dev: Optional[torch.Tensor] = None,
+    group_members: Optional[torch.Tensor] = None,
 ) -> None:
     """Attention of every group's decode queries over the group's shared prefix, once per group, left as split
     partials in `workspace` for the paged_decode call that follows with the same seq_lens / start_lens /
     max_splits / chunk and extra_splits[b] = ceil(prefix / key_chunk).  items / key_chunk_dev: the work list and
-    slice length in device memory, for captured launches (shared_prefix_items builds the list)."""
+    slice length in device memory, for captured launches (shared_prefix_items builds the list).  group_members:
+    batch indices of the members, group after group (group_first then indexes this list); None = the members of
+    group g are the consecutive batch entries group_first[g] .. + group_count[g] - 1."""
     _dev_bf16(q, "q")
     for t, name in ((req_pool_indices, "req_pool_indices"), (seq_lens, "seq_lens"), (start_lens, "start_lens"),
                     (group_first, "group_first"), (group_count, "group_count"), (group_prefix, "group_prefix")):
@@ -206,10 +209,13 @@ def shared_prefix_decode(
         _dev_i32(items, "items")
     if key_chunk_dev is not None:
         _dev_i32(key_chunk_dev, "key_chunk_dev")
+    if group_members is not None:
+        _dev_i32(group_members, "group_members")
     _check(_lib.msgl_shared_prefix_decode(
         q.data_ptr(), q.stride(0) if bs > 1 else Hq * D, k_cache.data_ptr(), v_cache.data_ptr(), cs,
         req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(), seq_lens.data_ptr(), start_lens.data_ptr(),
-        group_first.data_ptr(), group_count.data_ptr(), group_prefix.data_ptr(), ng, int(max_members), int(max_prefix), int(key_chunk),
+        group_first.data_ptr(), group_count.data_ptr(), group_prefix.data_ptr(),
+        group_members.data_ptr() if group_members is not None else None, ng, int(max_members), int(max_prefix), int(key_chunk),
         workspace.data_ptr(), workspace.numel() * workspace.element_size(), bs, Hq, Hkv, D, float(scale), int(max_splits),
         int(chunk_tokens), chunk_dev.data_ptr() if chunk_dev is not None else None,
         items.data_ptr() if items is not None else None, items.numel() if items is not None else 0,
@@ -217,9 +223,10 @@ def shared_prefix_decode(
 
 
 def shared_prefix_items(groups, heads_per_kv_head: int, key_chunk: int, capacity: int) -> Optional[List[int]]:
-    """Work list of shared_prefix_decode for `groups` = [(first, count, prefix length)]: one entry per (group, 128-row
+    """Work list of shared_prefix_decode for `groups` = [(members, prefix length)]: one entry per (group, 128-row
     tile of members x heads, key slice), padded with -1 to `capacity`; None when the list does not fit."""
     out = []
+    groups = [(0, len(members), plen) for members, plen in groups]
     for gi, (_, count, plen) in enumerate(groups):
         for rt in range(-(-count * heads_per_kv_head // 128)):
             for ks in range(-(-plen // key_chunk)):

@@ -205,17 +205,14 @@ class BatchInfo:
 
     # ------------------------------------------------------------------ bookkeeping used by callers
     def shared_groups(self) -> List[tuple]:
-        """Runs of neighbouring requests whose page-table rows start with the same cached prefix, as
-        (first index, count, prefix length); what the attention backend may compute once per run."""
-        groups, i, reqs = [], 0, self.reqs or []
-        while i < len(reqs):
-            j, key = i + 1, reqs[i].shared_key
-            while key is not None and j < len(reqs) and reqs[j].shared_key == key:
-                j += 1
-            if key is not None and j - i >= 2:
-                groups.append((i, j - i, key[0]))
-            i = j
-        return groups
+        """Requests of the batch whose page-table rows start with the same cached prefix, as (batch indices of the
+        members, prefix length) — what the attention backend may compute once per group.  Members need not be
+        neighbours; groups come in the order of their first member."""
+        by_key = {}
+        for i, r in enumerate(self.reqs or []):
+            if r.shared_key is not None:
+                by_key.setdefault(r.shared_key, []).append(i)
+        return [(tuple(m), key[0]) for key, m in by_key.items() if len(m) >= 2]
 
     def merge_batch(self, other: "BatchInfo") -> None:
         """batch_info.py:304-317."""

@@ -293,13 +293,13 @@ def test_decode_batch_on_a_shared_radix_prefix(ps, graph):
     toks_shared, groups, used = generate(True)
     toks_plain, _, used_plain = generate(False)
     hit = 200 - 200 % ps if ps > 1 else 200
-    assert groups == [(0, 3, hit)]
+    assert groups == [((0, 1, 2), hit)]
     assert all(used) and not any(used_plain)
     assert toks_shared == toks_plain and all(len(t) == new for t in toks_shared)
 
 
 def test_chained_and_replayed_steps_on_shared_prefixes():
-    """A decode batch with two runs of requests on shared prefixes (512 and 16 tokens): per-request reads (eager),
+    """A decode batch with two groups of requests on shared prefixes (512 and 16 tokens): per-request reads (eager),
     shared reads (eager), host-prepared graph replays and device-chained steps with shared reads all generate
     the same tokens."""
     from mini_sglang_amd.runtime import decode_loop
@@ -307,7 +307,7 @@ def test_chained_and_replayed_steps_on_shared_prefixes():
     from mini_sglang_amd.runtime.qwen3 import Qwen3Config
 
     ps, steps = 16, 12
-    lens, groups, prefix = [700, 650, 900, 300, 20], [0, 0, 0, 1, 1], [512, 16]
+    lens, groups, prefix = [700, 300, 650, 900, 20], [0, 1, 0, 0, 1], [512, 16]  # members interleaved in the batch
 
     def build(use_graph, share):
         torch.manual_seed(4321)
@@ -324,12 +324,12 @@ def test_chained_and_replayed_steps_on_shared_prefixes():
     mr, plain = build(False, False)
     decode_loop.decode_steps(mr, plain, steps)
     mr, shared = build(False, True)
-    assert shared.shared_groups() == [(0, 3, 512), (3, 2, 16)]
+    assert shared.shared_groups() == [((0, 2, 3), 512), ((1, 4), 16)]
     decode_loop.decode_steps(mr, shared, steps)
     assert mr.attn_backend.forward_metadata.shared is not None
     mr, replayed = build(True, True)
     decode_loop.decode_steps(mr, replayed, steps)
-    assert mr.attn_backend._graph_shared_key[1] == ((0, 3, 512), (3, 2, 16))
+    assert mr.attn_backend._graph_shared_key[1] == (((0, 2, 3), 512), ((1, 4), 16))
     mr, chained = build(True, True)
     loop = DeviceDecodeLoop(mr, chained, max_steps=16)
     loop.run(steps)

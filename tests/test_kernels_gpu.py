@@ -139,9 +139,10 @@ def run_decode_shared(case, page_size, groups, prefix, key_chunk, chunk, max_spl
     kc, vc = kvd[:, 0], kvd[:, 1]
     bs = len(groups)
     ng = max(groups) + 1
-    first = [groups.index(g) for g in range(ng)]
-    count = [groups.count(g) for g in range(ng)]
-    assert all(groups[first[g]: first[g] + count[g]] == [g] * count[g] for g in range(ng)), "members must be consecutive"
+    members = [[i for i, g in enumerate(groups) if g == gi] for gi in range(ng)]  # anywhere in the batch
+    count = [len(m) for m in members]
+    first = [sum(count[:g]) for g in range(ng)]
+    consecutive = all(m == list(range(m[0], m[0] + len(m))) for m in members)
     i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
     # a group of one has nothing to share: it stays with the per-request kernel
     gprefix = [prefix[g] if count[g] > 1 else 0 for g in range(ng)]
@@ -149,13 +150,29 @@ def run_decode_shared(case, page_size, groups, prefix, key_chunk, chunk, max_spl
     extra = i32([-(-gprefix[g] // key_chunk) for g in groups])
     q, r2t, idx, sl = case["q"].to(DEV), case["r2t"].to(DEV), case["req_idx"].to(DEV), case["seq_lens"].to(DEV)
     ws = torch.zeros(ops.decode_workspace_bytes(bs, q.shape[1], 128, max_splits), dtype=torch.uint8, device=DEV)
-    ops.shared_prefix_decode(q, kc, vc, r2t, idx, sl, start, i32(first), i32(count), i32(gprefix), max(count), max(max(gprefix), 1),
-                             key_chunk, 128 ** -0.5, ws, max_splits, chunk)
+    # consecutive members may be passed without the member list (group_first = batch index of the first member)
+    ops.shared_prefix_decode(q, kc, vc, r2t, idx, sl, start, i32([m[0] for m in members] if consecutive else first), i32(count),
+                             i32(gprefix), max(count), max(max(gprefix), 1), key_chunk, 128 ** -0.5, ws, max_splits, chunk,
+                             group_members=None if consecutive else i32([i for m in members for i in m]))
     plan = ops.decode_plan(sl, max_splits, chunk, start_lens=start) if planned else None
     out = ops.paged_decode(q, kc, vc, r2t, idx, sl, 128 ** -0.5, page_size, workspace=ws, max_splits=max_splits, chunk_tokens=chunk,
                            start_lens=start, extra_splits=extra, plan=plan)
     torch.cuda.synchronize()
     return out.cpu()
+
+
+def test_decode_shared_prefix_members_anywhere_in_the_batch():
+    """The members of a group need not be neighbours: three groups interleaved through the batch."""
+    ps = 16
+    groups = [0, 1, 0, 2, 1, 0, 1, 2, 0]
+    prefix = [512, 64, 1040]
+    seq = [prefix[g] + 1 + 37 * i for i, g in enumerate(groups)]
+    case = build_case(32, 8, ps, seq, seed=83, groups=groups, prefix=prefix)
+    base = run_decode(case, ps, max_splits=16, chunk_tokens=256)
+    check_decode(case, base)
+    out = run_decode_shared(case, ps, groups, prefix, key_chunk=512, chunk=256, max_splits=16, planned=True)
+    check_decode(case, out)
+    assert (out.float() - base.float()).abs().max().item() <= 2e-2
 
 
 @pytest.mark.parametrize("Hq,Hkv,page_size", [(32, 8, 16), (8, 1, 64), (16, 8, 1), (4, 4, 16)])
