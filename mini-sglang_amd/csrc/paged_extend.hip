@@ -729,5 +729,6 @@ extern "C" int msgl_shared_prefix_decode(const void* q, int64_t q_stride, const 
     g.dec.ws_ml = g.dec.ws_o + (size_t)bs * max_splits * Hq * D;
     const int64_t blocks = (items ? (int64_t)num_items : (int64_t)num_groups * g.row_tiles * g.key_splits) * Hkv;
     MSGL_REQUIRE(blocks <= 0x7fffffff, "msgl_shared_prefix_decode: grid too large");
-    return launch_extend<1, 3, true>(p, blocks, static_cast<hipStream_t>(stream), g);
+    // a slice is 8-16 key tiles: the two-slot ring (two work groups per CU) measured slightly ahead of the three-slot one
+    return launch_extend<1, 2, true>(p, blocks, static_cast<hipStream_t>(stream), g);
 }
