@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--e2e-steps", type=int, default=16)
     ap.add_argument("--e2e-eager", action="store_true", help="do not capture decode steps in hipGraphs")
     ap.add_argument("--allreduce-trial-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend under N > 1 (gloo: ranks may share a GPU, for rehearsals)")
     return ap.parse_args()
 
 
@@ -69,8 +70,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -234,6 +239,10 @@ def main():
     if world > 1 and not args.no_e2e:
         result["tp_allreduce"] = tp_allreduce_trial_isolated(world, rank, local_rank, barrier)
         xgmi_ok = bool(result["tp_allreduce"].get("validated"))
+    if world > 1 and args.dist_backend != "nccl" and not args.no_e2e:
+        # rehearsal on a CPU-side backend: it can neither be captured in a graph nor reduce bf16 tensors on the GPU
+        result["decode_e2e"] = {"skipped": f"whole-model decode needs the nccl backend, not {args.dist_backend}"}
+        args.no_e2e = True
     if not args.no_e2e:
         result["decode_e2e"] = decode_e2e(args, world, rank, barrier)
         import gc
@@ -561,7 +570,7 @@ def tp_allreduce_trial_isolated(world, rank, local_rank, barrier):
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     info["validated"] = bool(int(flag[0]))
     info["isolated"] = True
-    if info["validated"] and "sizes" in info:  # RCCL on the same sizes, in this process
+    if info["validated"] and "sizes" in info and dist.get_backend() == "nccl":  # RCCL on the same sizes, in this process
         for name, entry in info["sizes"].items():
             x = torch.zeros(int(name.split("x")[0]) * 4096, dtype=torch.bfloat16, device=dev)
             for _ in range(10):

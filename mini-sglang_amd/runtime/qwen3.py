@@ -185,7 +185,8 @@ class Qwen3ForCausalLM(nn.Module):
         _, tp = _tp()
         if tp > 1:
             parts = [torch.empty_like(logits) for _ in range(tp)]
-            dist.all_gather(parts, logits)
+            # a gather only copies: as bytes it runs on every backend, whatever that backend can reduce
+            dist.all_gather([p.view(torch.uint8) for p in parts], logits.view(torch.uint8))
             logits = torch.cat(parts, dim=-1)
         return logits
 
