@@ -24,6 +24,49 @@ def expected_sum(numel, seed, world):
     return acc.bfloat16()
 
 
+def tp_model(rank, world, dev):
+    """The Qwen3-shaped stack on HIP kernels, tensor parallel over `world` ranks, with every o_proj / down_proj /
+    embedding all-reduce on the direct-read kernels: prints the greedy tokens of the small end-to-end fixture case."""
+    import json
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import gen_golden as gg
+    from mini_sglang_amd import comm
+    from mini_sglang_amd.mem_cache import MHAKVPool, PageAllocator, ReqToTokenPool
+    from mini_sglang_amd.runtime.batch_info import BatchInfo, Req, SamplingParams
+    from mini_sglang_amd.runtime.model_runner import ModelConfig, ModelRunner, ServerArgs
+    from mini_sglang_amd.runtime.qwen3 import Qwen3Config
+
+    name, steps = "tiny_ps16", 24
+    cfg_kw, ps, (pseed, plens), nt, wseed, wstd, estd, succ = gg.E2E_CASES[name]
+    cfg = Qwen3Config(**cfg_kw)
+    args = ServerArgs(page_size=ps, device=str(dev), disable_cuda_graph=True, max_num_reqs=8, random_seed=wseed, weight_std=wstd,
+                      embed_std=estd, successor_head=succ)
+    pages = 1024 // ps
+    r2t = ReqToTokenPool(8, cfg.max_position_embeddings, ps, str(dev))
+    pa = PageAllocator(pages, ps)
+    kv = MHAKVPool(pages * ps, ps, torch.bfloat16, cfg.num_key_value_heads // world, cfg.head_dim, cfg.num_hidden_layers, str(dev))
+    mr = ModelRunner(ModelConfig(cfg), args, gpu_id=dev.index, tp_rank=rank, tp_size=world, req_to_token_pool=r2t, page_allocator=pa,
+                     kv_cache_pool=kv)
+    ar = comm.enable_xgmi_allreduce(max_bytes=1 << 20)
+    prompts = gg.e2e_prompts(pseed, plens, cfg.vocab_size)
+    reqs = [Req(i, p, SamplingParams(0.0)) for i, p in enumerate(prompts)]
+    batch = BatchInfo.init_new(reqs, r2t, pa, kv)
+    batch.prepare_for_extend()
+    lg, _ = mr.forward_generate(batch)
+    mr.process_result(batch, lg)
+    for _ in range(steps - 1):
+        batch.prepare_for_decode()
+        lg, _ = mr.forward_generate(batch)
+        mr.process_result(batch, lg)
+    ar.check()
+    toks = [r.token_ids[len(p):] for r, p in zip(reqs, prompts)]
+    print("TOKENS " + json.dumps(toks), flush=True)
+    comm.disable_xgmi_allreduce()
+    dist.destroy_process_group()
+    sys.exit(0)
+
+
 def main():
     import faulthandler
 
@@ -35,6 +78,8 @@ def main():
     torch.cuda.set_device(dev)
     from mini_sglang_amd.comm import XgmiAllReduce
 
+    if len(sys.argv) > 1 and sys.argv[1] == "tp-model":
+        return tp_model(rank, world, dev)
     comm = XgmiAllReduce(max_bytes=4 << 20)
     sizes = [8, 512, 3 * 4096 + 8, 131072 + 8, 1 << 20]
     bad = []

@@ -17,6 +17,21 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def test_tp2_model_on_direct_read_allreduce_matches_reference_stream():
+    """The whole stack, tensor parallel over two ranks (KV heads, MLP columns and vocabulary sharded), every
+    all-reduce of hidden states on the direct-read kernels, must generate the single-rank greedy stream of the
+    reference fixture, on both ranks."""
+    import json
+
+    import golden_cases as gc
+
+    outs = _run_ranks(2, "tp-model")
+    fx = gc.load("e2e_tiny_ps16.pt")
+    for out in outs:
+        line = [ln for ln in out.splitlines() if ln.startswith("TOKENS ")][-1]
+        assert json.loads(line[7:]) == fx["tokens"][:, :24].tolist()
+
+
 def _run_ranks(world, *args):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
                HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
@@ -37,6 +52,7 @@ def _run_ranks(world, *args):
     report = "\n".join(f"--- rank {r} (exit {p.returncode})\n{o[-2000:]}" for r, (p, o) in enumerate(zip(procs, outs)))
     print(report)
     assert not failed and all(p.returncode == 0 for p in procs), report
+    return outs
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
