@@ -37,10 +37,10 @@ def ulp_diff_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return (key(a.cpu()) - key(b.cpu())).abs()
 
 
-def assert_close_fp64(out: torch.Tensor, exact: torch.Tensor, what: str):
-    """bf16 output vs an fp64 evaluation: one bf16 ulp (2^-8 relative) plus 4e-3 absolute."""
+def assert_close_fp64(out: torch.Tensor, exact: torch.Tensor, what: str, slack: float = 1.0):
+    """bf16 output vs an fp64 evaluation: one bf16 ulp (2^-8 relative) plus 4e-3 absolute, times `slack`."""
     err = (out.double() - exact).abs()
-    bound = 4e-3 + exact.abs() * 2.0 ** -8
+    bound = slack * (4e-3 + exact.abs() * 2.0 ** -8)
     worst = (err - bound).max().item()
     assert worst <= 0, f"{what} vs fp64: exceeds bound by {worst} (max abs err {err.max().item()})"
 
@@ -323,7 +323,9 @@ def check_extend(case, out):
         S, P, n = int(case["seq_lens"][b]), int(case["prefix"][b]), int(case["inp"][b])
         exact = orc.paged_attention_fp64(case["q"][start: start + n], kc, vc, case["r2t"][b, :S], scale,
                                          q_positions=torch.arange(P, P + n))
-        assert_close_fp64(out[start: start + n], exact, f"request {b} (prefix {P}, new {n})")
+        # the extend kernel rounds the probabilities to bf16 for the P.V product (as the reference's SDPA does); on rows
+        # with a handful of keys those roundings do not average out, hence twice the decode bound
+        assert_close_fp64(out[start: start + n], exact, f"request {b} (prefix {P}, new {n})", slack=2.0)
         start += n
 
 

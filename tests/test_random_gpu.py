@@ -1,6 +1,7 @@
 """Seeded random shapes through the decode and extend entry points against the oracle: lengths, page sizes, head
 layouts, split sizes, launch plans and shared-prefix groups drawn together, so that combinations no hand-written
 case lists get exercised (each case stays small enough for the CPU oracle)."""
+import os
 import random
 
 import pytest
@@ -10,10 +11,11 @@ import test_kernels_gpu as tk
 
 pytestmark = pytest.mark.gpu
 DEV = tk.DEV
+MORE = int(os.environ.get("MSGL_RANDOM_CASES", "0"))  # extra seeds per test for an occasional longer soak
 HEADS = [(32, 8), (16, 8), (8, 1), (4, 1), (16, 4), (8, 2), (64, 8), (8, 8)]
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(32 + MORE))
 def test_decode_random_case(seed):
     rng = random.Random(1000 + seed)
     ops = tk._ops()
@@ -34,7 +36,7 @@ def test_decode_random_case(seed):
     assert torch.equal(tk.run_decode(case, ps, max_splits=max_splits, chunk_dev=cd), base)
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(20 + MORE))
 def test_decode_shared_prefix_random_case(seed):
     rng = random.Random(2000 + seed)
     Hq, Hkv = rng.choice([(32, 8), (16, 8), (8, 1), (4, 1), (16, 4), (8, 8)])
@@ -55,7 +57,7 @@ def test_decode_shared_prefix_random_case(seed):
     tk.check_decode(case, out)
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(20 + MORE))
 def test_extend_random_case(seed):
     rng = random.Random(3000 + seed)
     Hq, Hkv = rng.choice([(32, 8), (16, 8), (8, 1), (4, 1), (4, 4), (16, 4)])
