@@ -147,7 +147,10 @@ class HipAttnBackend(AttentionBackend):
         most_extra = max(extra)
         own_splits = max(1, splits_for_batch(bs) - most_extra)
         kv_heads = int(getattr(self.kv_cache_pool, "head_num", 8))
-        chunk = ops.pick_split_planned(rest, own_splits, kv_heads, self._cus)
+        key = ("shared", bs, own_splits, sum(rest) // (64 * bs), max(rest) // 64, tuple(groups))
+        if self._planned_split[0] != key:  # the schedule model costs milliseconds: keep its answer while the batch barely changes
+            self._planned_split = (key, ops.pick_split_planned(rest, own_splits, kv_heads, self._cus))
+        chunk = max(self._planned_split[1], -(-(-(-max(rest) // own_splits)) // 16) * 16)
         md = HipAttnMetadata(chunk_tokens=chunk, max_splits=-(-max(rest) // chunk) + most_extra)
         md.reuse_lens = getattr(batch, "shared_prefix_lens", None)
         first, flat = _flatten_groups(groups)
