@@ -250,6 +250,10 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         result["decode_e2e_mixed"] = decode_e2e_mixed(args, world, rank, barrier)
+        if world == 1:
+            gc.collect()
+            torch.cuda.empty_cache()
+            result["decode_e2e_small"] = decode_e2e_small(args, barrier)
         if xgmi_ok:  # the same steps with the o_proj / down_proj / embedding all-reduces on direct peer reads
             from mini_sglang_amd import comm
 
@@ -411,6 +415,23 @@ def extend_attention(args, world, rank):
                 "TFLOPs_per_gpu": round(tf, 1),
                 "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4)}}
     except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def decode_e2e_small(args, barrier):
+    """Whole-model decode tok/s of the small configuration: Qwen3-0.6B shape, batch 64 x 2048 ctx, page_size 1
+    (per-token page table, fully scattered slots), one GPU, hipGraph replay."""
+    from mini_sglang_amd.runtime import decode_loop
+    from mini_sglang_amd.runtime.qwen3 import Qwen3Config
+
+    try:
+        bs, ctx, ps, steps = 64, 2048, 1, 24
+        mr, batch = decode_loop.build_decode_state(Qwen3Config.qwen3_0_6b(), bs, ctx, ps, 2 * steps + 24, use_graph=not args.e2e_eager)
+        dt = decode_loop.time_decode(mr, batch, steps, 4, barrier=barrier)
+        return {"model": "Qwen3-0.6B shape, random weights", "batch": bs, "ctx": ctx, "page_size": ps, "tp": 1,
+                "tok_per_s": round(bs * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+                "hip_graph": not args.e2e_eager}
+    except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
