@@ -361,6 +361,9 @@ def other_decode_configs(args, world, rank):
     try:
         if world == 1:
             run("qwen3_0.6b_bs64_ctx2048_ps1", 16, 8, 1, [2048] * 64, layers=8)
+            # the long-context configuration: one TP-8 shard of Qwen3-32B (8 q / 1 kv head), page_size 64, 128k contexts
+            run("qwen3_32b_tp8_shard_bs1_ctx131072_ps64", 8, 1, 64, [131072], layers=8, steps=20)
+            run("qwen3_32b_tp8_shard_bs8_ctx131072_ps64", 8, 1, 64, [131072] * 8, layers=4, steps=12)
         lens = workload.mixed_lengths(256, 1024, 32768, 3)
         groups = [i // 16 for i in range(256)]
         prefix = [1024 * (1 + g % 4) for g in range(16)]
@@ -381,39 +384,45 @@ def extend_attention(args, world, rank):
     from mini_sglang_amd import ops
     from mini_sglang_amd.runtime import synth, workload
 
-    try:
-        D, ps, Sq = 128, args.page_size, 16384
-        Hq, Hkv = args.hq // world, args.hkv // world
-        pages = -(-Sq // ps) + 8
-        pt = workload.make_page_table([Sq], ps, pages, seed=5, scatter=True)
-        dev = torch.device("cuda", torch.cuda.current_device())
+    D = 128
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def measure(Hq, Hkv, ps, Sq, prefix, steps=10):
+        S = prefix + Sq
+        pages = -(-S // ps) + 8
+        pt = workload.make_page_table([S], ps, pages, seed=5, scatter=True)
         kv = synth.normal(((pages + 1) * ps, 2, Hkv, D), 31 + rank, device=dev)
         q = synth.normal((Sq, Hq, D), 32 + rank, device=dev)
         out = torch.empty_like(q)
         r2t = pt.req_to_token.to(dev)
         idx = torch.zeros(1, dtype=torch.int32, device=dev)
         cu = torch.tensor([0, Sq], dtype=torch.int32, device=dev)
-        pre = torch.zeros(1, dtype=torch.int32, device=dev)
+        pre = torch.tensor([prefix], dtype=torch.int32, device=dev)
 
         def f():
-            ops.paged_extend(q, kv[:, 0], kv[:, 1], r2t, idx, cu, pre, Sq, D ** -0.5, ps, out=out)
+            ops.paged_extend(q, kv[:, 0], kv[:, 1], r2t, idx, cu, pre, Sq, D ** -0.5, ps, out=out, max_seqlen_k=S)
 
         for _ in range(3):
             f()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        steps = 10
         e0.record()
         for _ in range(steps):
             f()
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / steps
-        flops = 4 * Hq * D * Sq * (Sq + 1) / 2
-        tf = flops / (ms * 1e-3) / 1e12
-        return {"workload": f"one {Sq}-token prompt, {Hq} q / {Hkv} kv heads per GPU, page_size {ps}", "ms_per_launch": round(ms, 4),
+        tf = 4 * Hq * D * Sq * (prefix + (Sq + 1) / 2) / (ms * 1e-3) / 1e12
+        what = f"one {Sq}-token prompt" + (f" on a {prefix}-token cached prefix" if prefix else "")
+        return {"workload": f"{what}, {Hq} q / {Hkv} kv heads per GPU, page_size {ps}", "ms_per_launch": round(ms, 4),
                 "TFLOPs_per_gpu": round(tf, 1),
                 "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4)}}
+
+    try:
+        res = measure(args.hq // world, args.hkv // world, args.page_size, 16384, 0)
+        if world == 1:  # the long-context configuration's prefill: one TP-8 shard of Qwen3-32B (8 q / 1 kv head), page_size 64
+            res["qwen3_32b_tp8_shard"] = [measure(8, 1, 64, 16384, 0), measure(8, 1, 64, 4096, 65536, steps=6)]
+        return res
     except Exception as e:
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
