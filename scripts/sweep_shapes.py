@@ -78,9 +78,10 @@ if "cfg3i" in which:
     run("cfg3i 8B bs256 8k ps16", 32, 8, 16, [8192] * 256)
 if "cfg3ii" in which:
     lens = workload.mixed_lengths(256, 1024, 32768, 3)
-    # 16 groups x 16 requests sharing a page-aligned 1-4k prefix
-    groups = [i // 16 for i in range(256)]
-    prefix = [1024 * (1 + g % 4) for g in range(16)]
+    # groups of GROUP (default 16) requests sharing a page-aligned 1-4k prefix
+    gsz = int(os.environ.get("GROUP", "16"))
+    groups = [i // gsz for i in range(256)]
+    prefix = [1024 * (1 + g % 4) for g in range(256 // gsz)]
     lens = [max(l, prefix[g] + 16) for l, g in zip(lens, groups)]
     tot = sum(lens)
     run("cfg3ii 8B bs256 mixed 1k-32k ps16 radix-shared", 32, 8, 16, lens, groups, prefix, layers=2)
