@@ -629,6 +629,9 @@ def tp_allreduce_trial(world, rank, barrier):
     info = {"validated": False}
     try:
         comm = XgmiAllReduce(max_bytes=8 << 20)  # raises on every rank or on none
+        # ranks that share a device (a one-GPU rehearsal) get every call issued step by step: results are checked
+        # all the same, the times then say nothing about a node with a GPU per rank
+        info["stepped"] = bool(comm.stepped)
         dev = torch.device("cuda", torch.cuda.current_device())
         cases = []
         for n in (4096, 64 * 4096, 256 * 4096):  # torch collectives first ...

@@ -58,9 +58,29 @@ int msgl_ar_open(msgl_ar_t* c, const void* all_handles);
 int msgl_ar_allreduce_bf16(msgl_ar_t* c, const void* in, void* out, int64_t numel,
                            size_t one_shot_bytes, void* stream);
 
+/* The same call issued step by step, for set-ups in which the ranks' kernels
+ * cannot be relied upon to run at the same time (several ranks sharing ONE
+ * device in a rehearsal: a kernel that spins for its peer may keep the peer's
+ * kernel from starting).  msgl_ar_num_steps gives the number of steps of the
+ * form the call would take (2 or 3; 0 for numel <= 0).  Every rank issues step
+ * s = 0, 1, .. with the same arguments, and between two steps every rank waits
+ * until step s has COMPLETED on all ranks (stream synchronisation + a host
+ * barrier); the device-side waits then find their flags raised.  Same device
+ * code, flags, call numbering and result as the one-launch call.  The reference
+ * has no counterpart (its all-reduce is NCCL's). */
+int msgl_ar_num_steps(msgl_ar_t* c, int64_t numel, size_t one_shot_bytes);
+int msgl_ar_allreduce_bf16_step(msgl_ar_t* c, const void* in, void* out, int64_t numel,
+                                size_t one_shot_bytes, int step, void* stream);
+
+/* How long a kernel waits for a peer before it gives up (default 1000 ms;
+ * 1 .. 60000).  Applies to calls issued afterwards. */
+int msgl_ar_set_timeout_ms(msgl_ar_t* c, int milliseconds);
+
 /* Synchronises the device and returns 0, or MSGL_E_LAUNCH when a kernel gave up
- * waiting for a peer (a rank died or the ranks disagree on the call sequence);
- * the waiting is bounded so that no kernel spins forever. */
+ * waiting for a peer (a rank died, the ranks disagree on the call sequence, or
+ * the peer's kernel never ran beside this one); the waiting is bounded so that
+ * no kernel spins forever, and a work group that gave up signals nothing
+ * further, so the peers' waits of that call run out as well. */
 int msgl_ar_check(msgl_ar_t* c);
 
 /* Unmaps the peers and frees this rank's memory.  The caller makes sure (with a

@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSGL_HIP_LIB", os.path.join(_HERE, "libmsgl_hip.so"))
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # name -> (restype, argtypes); mirrors include/msgl_hip.h and include/msgl_comm.h one to one
 SIGNATURES = {
@@ -68,6 +68,9 @@ SIGNATURES = {
     "msgl_ar_export": (c_int, [c_void_p, c_void_p]),
     "msgl_ar_open": (c_int, [c_void_p, c_void_p]),
     "msgl_ar_allreduce_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_size_t, c_void_p]),
+    "msgl_ar_num_steps": (c_int, [c_void_p, c_int64, c_size_t]),
+    "msgl_ar_allreduce_bf16_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_size_t, c_int, c_void_p]),
+    "msgl_ar_set_timeout_ms": (c_int, [c_void_p, c_int]),
     "msgl_ar_check": (c_int, [c_void_p]),
     "msgl_ar_destroy": (c_int, [c_void_p]),
 }

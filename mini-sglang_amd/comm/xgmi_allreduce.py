@@ -7,6 +7,12 @@ One process per GPU.  ``XgmiAllReduce(group)`` allocates this rank's staging mem
 through the process group it is given (one all_gather of 128 bytes), and maps the peers.  ``all_reduce(t)`` is one
 kernel launch on the current stream and can be captured in a hipGraph.  Messages longer than the communicator's
 ``max_bytes`` (prefill-sized activations, bandwidth-bound) go to the process group's own all-reduce (RCCL).
+
+The one-launch form has every rank's kernel wait for its peers' kernels, which is sound when each rank owns a GPU.
+When several ranks share ONE device (a rehearsal on a single-GPU machine) nothing guarantees that kernels of two
+processes run at the same time, so the communicator then issues every call step by step
+(``msgl_ar_allreduce_bf16_step``) and crosses the protocol's synchronisation points on the host: same device code,
+flags and results, not capturable.  ``stepped=None`` picks that mode exactly when two ranks report the same device.
 """
 from __future__ import annotations
 
@@ -25,7 +31,7 @@ MAX_WORLD = 8
 
 class XgmiAllReduce:
     def __init__(self, group=None, max_bytes: int = 8 << 20, device: Optional[torch.device] = None,
-                 one_shot_bytes: int = 0):
+                 one_shot_bytes: int = 0, stepped: Optional[bool] = None, timeout_ms: int = 0):
         if not dist.is_initialized():
             raise RuntimeError("XgmiAllReduce needs an initialised torch.distributed process group")
         self.group = group
@@ -44,16 +50,19 @@ class XgmiAllReduce:
         with torch.cuda.device(self.device):
             try:
                 _capi.check(_lib.msgl_ar_create(self.rank, self.world, self.max_bytes, ctypes.byref(self._h)))
+                if timeout_ms:
+                    _capi.check(_lib.msgl_ar_set_timeout_ms(self._h, int(timeout_ms)))
                 mine = ctypes.create_string_buffer(EXPORT_BYTES)
                 _capi.check(_lib.msgl_ar_export(self._h, mine))
                 payload = mine.raw
             except Exception as e:  # noqa: BLE001 - reported below, on every rank
                 problem = f"rank {self.rank}: {e}"
             everyone = [None] * self.world
-            dist.all_gather_object(everyone, (payload, problem), group=group)  # also: every rank has zeroed its flags
-            if all(p == "" or p is None for _, p in everyone) and all(len(h) == EXPORT_BYTES for h, _ in everyone):
+            where = _device_identity(self.device)
+            dist.all_gather_object(everyone, (payload, problem, where), group=group)  # also: every rank has zeroed its flags
+            if all(p == "" or p is None for _, p, _ in everyone) and all(len(h) == EXPORT_BYTES for h, _, _ in everyone):
                 try:
-                    _capi.check(_lib.msgl_ar_open(self._h, b"".join(h for h, _ in everyone)))
+                    _capi.check(_lib.msgl_ar_open(self._h, b"".join(h for h, _, _ in everyone)))
                 except Exception as e:  # noqa: BLE001
                     problem = f"rank {self.rank}: {e}"
             else:
@@ -66,6 +75,12 @@ class XgmiAllReduce:
                 _lib.msgl_ar_destroy(self._h)
                 self._h = ctypes.c_void_p()
             raise RuntimeError("XgmiAllReduce setup failed: " + "; ".join(failures))
+        places = [w for _, _, w in everyone]
+        self.shared_device = len(set(places)) < len(places)
+        self.stepped = self.shared_device if stepped is None else bool(stepped)
+
+    def set_timeout_ms(self, milliseconds: int) -> None:
+        _capi.check(_lib.msgl_ar_set_timeout_ms(self._h, int(milliseconds)))
 
     def fits(self, t: torch.Tensor) -> bool:
         return (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.numel() % 8 == 0
@@ -79,8 +94,21 @@ class XgmiAllReduce:
         out = t if out is None else out
         if out is not t and not (self.fits(out) and out.numel() == t.numel()):
             raise ValueError("XgmiAllReduce.all_reduce: out must match the input")
-        _capi.check(_lib.msgl_ar_allreduce_bf16(self._h, t.data_ptr(), out.data_ptr(), t.numel(), self.one_shot_bytes,
-                                                torch.cuda.current_stream().cuda_stream))
+        stream = torch.cuda.current_stream()
+        if not self.stepped:
+            _capi.check(_lib.msgl_ar_allreduce_bf16(self._h, t.data_ptr(), out.data_ptr(), t.numel(), self.one_shot_bytes,
+                                                    stream.cuda_stream))
+            return out
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("XgmiAllReduce: ranks that share a device run the call step by step with host barriers "
+                               "in between, which a graph cannot capture")
+        steps = int(_lib.msgl_ar_num_steps(self._h, t.numel(), self.one_shot_bytes))
+        for step in range(steps):
+            _capi.check(_lib.msgl_ar_allreduce_bf16_step(self._h, t.data_ptr(), out.data_ptr(), t.numel(), self.one_shot_bytes,
+                                                         step, stream.cuda_stream))
+            if step + 1 < steps:  # every rank's step has completed before anybody's next one looks at the flags
+                stream.synchronize()
+                dist.barrier(group=self.group)
         return out
 
     def check(self) -> None:
@@ -93,6 +121,17 @@ class XgmiAllReduce:
             dist.barrier(group=self.group)  # nobody is still reading this rank's memory
             _lib.msgl_ar_destroy(self._h)
             self._h = ctypes.c_void_p()
+
+
+def _device_identity(device: torch.device) -> str:
+    """Something two ranks have in common exactly when they sit on the same physical GPU."""
+    props = torch.cuda.get_device_properties(device)
+    ident = getattr(props, "uuid", None)
+    if ident is None:
+        ident = f"{getattr(props, 'pci_bus_id', device.index)}:{getattr(props, 'pci_device_id', 0)}:{getattr(props, 'pci_domain_id', 0)}"
+    import socket
+
+    return f"{socket.gethostname()}/{ident}"
 
 
 _active: Optional[XgmiAllReduce] = None

@@ -76,14 +76,28 @@ def _worker(rank, world, port, name, steps, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
+def _spawn_with_deadline(fn, args, nprocs, seconds):
+    """mp.spawn with a time limit of its own (no plugin needed): ranks still alive at the deadline are ended and
+    the test fails."""
+    import time
+
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    deadline = time.monotonic() + seconds
+    while not ctx.join(timeout=5):
+        if time.monotonic() > deadline:
+            for p in ctx.processes:
+                if p.is_alive():
+                    p.terminate()
+            pytest.fail(f"ranks still running after {seconds} s")
+
+
 def test_tp2_gloo_matches_reference_stream(tmp_path):
     import golden_cases as gc
 
     name, steps = "tiny_ps16", 24
     out = str(tmp_path / "tp2.pt")
     port = 29650 + os.getpid() % 200
-    mp.spawn(_worker, args=(2, port, name, steps, out), nprocs=2, join=True)
+    _spawn_with_deadline(_worker, (2, port, name, steps, out), 2, 600)
     got = torch.load(out, weights_only=True)
     fx = gc.load(f"e2e_{name}.pt")
     assert torch.equal(got["tokens"], fx["tokens"][:, :steps])
