@@ -42,6 +42,8 @@ class HipAttnMetadata:
     max_seqlen_q: int = 0
     max_seqlen_k: int = 0
     extend_plan: Optional[torch.Tensor] = None  # launch order of the (request, query tile) items, longest first
+    # metadata of a captured batch size: its launches use the workspace that was sized before the first capture
+    static: bool = False
 
 
 # work items of the shared-prefix kernel in a captured launch (times the kv heads = work groups; one round of the chip when idle)
@@ -63,8 +65,18 @@ class HipAttnBackend(AttentionBackend):
         self.req_to_token_pool = model_runner.req_to_token_pool
         self.kv_cache_pool = model_runner.kv_cache_pool
         self.page_size = model_runner.page_size
-        self.max_context_len = model_runner.model_config.max_context_len
-        self._workspace: Optional[torch.Tensor] = None
+        cfg = model_runner.model_config
+        self.max_context_len = cfg.max_context_len
+        # this rank's heads, as the reference shards them (mini_sglang/models/qwen3.py:42-46)
+        tp_size = int(getattr(model_runner, "tp_size", 1) or 1)
+        self.num_heads = cfg.num_heads // tp_size
+        self.num_kv_heads = max(1, cfg.num_kv_heads // tp_size)
+        self.head_dim = cfg.head_dim
+        # Two split workspaces.  Captured launches have the address of theirs baked in, so that one is allocated
+        # once, in init_cuda_graph_state, for the worst case over all batch sizes, and never again.  Eager launches
+        # use a buffer of their own that grows on demand.
+        self._graph_workspace: Optional[torch.Tensor] = None
+        self._eager_workspace: Optional[torch.Tensor] = None
         # K/V rows are read once per step: stream them past the caches (non-temporal), keeping only the
         # prefix positions that several requests share cacheable
         self.kv_stream = True
@@ -84,21 +96,28 @@ class HipAttnBackend(AttentionBackend):
         self.decode_graph_metadata: Dict[int, HipAttnMetadata] = {}
 
     # ------------------------------------------------------------------ helpers
-    def _workspace_for(self, bs: int, Hq: int, D: int, max_splits: int) -> Optional[torch.Tensor]:
-        if max_splits <= 1:
+    def _workspace_for(self, md: HipAttnMetadata, bs: int, Hq: int, D: int) -> Optional[torch.Tensor]:
+        if md.max_splits <= 1:
             return None
-        need = ops.decode_workspace_bytes(bs, Hq, D, max_splits)
-        if self._workspace is None or self._workspace.numel() < need:
+        need = ops.decode_workspace_bytes(bs, Hq, D, md.max_splits)
+        if md.static:
+            ws = self._graph_workspace
+            if ws is None or ws.numel() < need:
+                raise RuntimeError(f"captured decode step needs a {need}-byte split workspace but init_cuda_graph_state "
+                                   f"sized {0 if ws is None else ws.numel()} bytes ({Hq} query heads here, {self.num_heads} announced)")
+            return ws
+        if self._eager_workspace is None or self._eager_workspace.numel() < need:
             if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("decode workspace must be sized before graph capture (init_cuda_graph_state)")
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._workspace
+                raise RuntimeError("an eager decode workspace cannot grow during graph capture; captured steps take their "
+                                   "metadata from init_forward_metadata_capture_cuda_graph")
+            self._eager_workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._eager_workspace
 
     def _decode_split(self, seq_lens_cpu: torch.Tensor, bs: int, max_splits: int):
         """(tokens per split, ragged).  A batch whose longest request is well above the average is launched in
         planned order, with the split size a host-side model of that schedule likes best; the model costs a few
         milliseconds, so its answer is kept until the batch has grown by 64 tokens per request or changed."""
-        kv_heads = int(getattr(self.kv_cache_pool, "head_num", 8))
+        kv_heads = self.num_kv_heads
         longest, total = int(seq_lens_cpu.max()), int(seq_lens_cpu.sum())
         if bs == 1 or longest * bs <= 1.25 * total:
             return ops.pick_split(longest, total, bs, max_splits, kv_heads), False
@@ -146,7 +165,7 @@ class HipAttnBackend(AttentionBackend):
         rest = [max(1, s - p) for s, p in zip(lens, start)]
         most_extra = max(extra)
         own_splits = max(1, splits_for_batch(bs) - most_extra)
-        kv_heads = int(getattr(self.kv_cache_pool, "head_num", 8))
+        kv_heads = self.num_kv_heads
         key = ("shared", bs, own_splits, sum(rest) // (64 * bs), max(rest) // 64, tuple(groups))
         if self._planned_split[0] != key:  # the schedule model costs milliseconds: keep its answer while the batch barely changes
             self._planned_split = (key, ops.pick_split_planned(rest, own_splits, kv_heads, self._cus))
@@ -181,10 +200,9 @@ class HipAttnBackend(AttentionBackend):
         k_cache, v_cache = self.kv_cache_pool.get_kv_buffer(layer.layer_id)
         bs = q.shape[0]
         q3 = _as_heads(q, layer.num_heads, layer.head_dim)
-        ws = self._workspace_for(bs, layer.num_heads, layer.head_dim, md.max_splits)
+        ws = self._workspace_for(md, bs, layer.num_heads, layer.head_dim)
         sh = md.shared
         if sh is not None:
-            self._heads_per_kv_head = layer.num_heads // layer.num_kv_heads
             ops.shared_prefix_decode(q3, k_cache, v_cache, self.req_to_token_pool.req_to_token, batch.req_pool_indices, batch.seq_lens,
                                      sh["start"], sh["first"], sh["count"], sh["prefix"], sh["max_members"], sh["max_prefix"],
                                      sh["key_chunk"], layer.scale, ws, md.max_splits, md.chunk_tokens, chunk_dev=md.chunk_dev,
@@ -198,9 +216,11 @@ class HipAttnBackend(AttentionBackend):
         return o.view(bs, layer.num_heads * layer.head_dim)
 
     # ------------------------------------------------------------------ graph hooks
-    def init_cuda_graph_state(self, max_bs: int, num_heads: Optional[int] = None, head_dim: int = 128):
-        """Static state shared by all captured batch sizes: the 4-byte split-size word and a workspace large
-        enough for every (bs, splits_for_batch(bs)) pair (compare fa3_attn_backend.py:154-175)."""
+    def init_cuda_graph_state(self, max_bs: int):
+        """Static state shared by all captured batch sizes (compare fa3_attn_backend.py:154-175): the 4-byte
+        split-size word, the launch-order and shared-prefix buffers, and the split workspace, sized here once for the
+        worst (bs, splits_for_batch(bs)) pair — bs * splits is not monotone in bs — from the head counts the
+        constructor read off the runner's model config."""
         most_items = max(bs * splits_for_batch(bs) for bs in range(1, max_bs + 1))
         self.decode_graph_vars = {"chunk": torch.full((1,), 1 << 20, dtype=torch.int32, device=self.device),
                                   "reuse_lens": torch.zeros(max_bs, dtype=torch.int32, device=self.device),
@@ -215,17 +235,14 @@ class HipAttnBackend(AttentionBackend):
         self._graph_shared_key = None
         self.decode_graph_metadata = {}
         self.decode_graph_metadata_shared = {}
-        if num_heads is None:
-            num_heads = getattr(self, "graph_num_heads", None)
-        if num_heads is not None:
-            worst = max(ops.decode_workspace_bytes(bs, num_heads, head_dim, splits_for_batch(bs)) for bs in range(1, max_bs + 1))
-            self._workspace = torch.empty(worst, dtype=torch.uint8, device=self.device)
+        worst = max(ops.decode_workspace_bytes(bs, self.num_heads, self.head_dim, splits_for_batch(bs)) for bs in range(1, max_bs + 1))
+        self._graph_workspace = torch.empty(max(worst, 16), dtype=torch.uint8, device=self.device)
 
     def init_forward_metadata_capture_cuda_graph(self, bs: int, forward_mode):
         if forward_mode.is_extend():
             raise NotImplementedError("extend is not captured in a graph")
         splits = splits_for_batch(bs)
-        md = HipAttnMetadata(max_splits=splits, chunk_dev=self.decode_graph_vars["chunk"],
+        md = HipAttnMetadata(static=True, max_splits=splits, chunk_dev=self.decode_graph_vars["chunk"],
                              reuse_lens=self.decode_graph_vars["reuse_lens"][:bs],
                              decode_plan=self.decode_graph_vars["plan"][: bs * splits] if splits > 1 else None)
         if md.decode_plan is not None:  # valid for any lengths until the first refresh
@@ -303,7 +320,7 @@ class HipAttnBackend(AttentionBackend):
         list or their slices do not fit what was captured."""
         v = self.decode_graph_vars
         groups = [g for g in self._graph_groups if max(g[0]) < bs] if self.share_prefix_reads else []
-        heads = getattr(self, "_heads_per_kv_head", 4)
+        heads = self.num_heads // self.num_kv_heads
         key_chunk, items = 1024, None
         while groups:
             items = ops.shared_prefix_items(groups, heads, key_chunk, GRAPH_SHARED_ITEMS)

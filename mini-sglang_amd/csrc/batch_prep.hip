@@ -5,8 +5,11 @@
 //
 // One work group of 1024 threads walks the batch in chunks.  Pass 1 counts the requests that start a new
 // page; if the free list cannot serve them all, or a request would outgrow its page-table row, the step is
-// refused as a whole (status != 0, nothing written).  Pass 2 assigns pages in batch order with a block-wide
-// exclusive scan, so request i gets exactly the page the host allocator would have handed it.
+// refused as a whole: status != 0, lengths, table and free list untouched, and every out_cache_loc entry
+// pointed at the dummy slot 0, so that the forward pass that follows in a captured step overwrites no
+// request's K/V.  A refusal is sticky (every later step is refused too) until the host clears status.
+// Pass 2 assigns pages in batch order with a block-wide exclusive scan, so request i gets exactly the page
+// the host allocator would have handed it.
 #include "msgl_common.h"
 
 namespace msgl {
@@ -69,8 +72,11 @@ __global__ __launch_bounds__(kPrepThreads) void decode_prepare_kernel(PrepParams
         block_scan_flags(need, lds_wave, chunk_total);
         need_total += chunk_total;
     }
-    const int refuse = __syncthreads_or(too_long) ? 2 : (need_total > end - head ? 1 : 0);
+    const int earlier = *p.status;
+    const int refuse = earlier ? earlier : (__syncthreads_or(too_long) ? 2 : (need_total > end - head ? 1 : 0));
     if (refuse) {
+        for (int i = tid; i < p.bs; i += kPrepThreads) p.out_loc[i] = 0;
+        __syncthreads();  // every thread has read the status word
         if (tid == 0) *p.status = refuse;
         return;
     }

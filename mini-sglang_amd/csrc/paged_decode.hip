@@ -111,9 +111,11 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
     // Table entry (entries) of own tile n, always from a valid position so that the load is
     // unconditional: PAGED16 -> the slot of the tile's first position (wave uniform, a scalar load);
     // otherwise lane c holds the slot of the tile's c-th token.
+    // A tile that starts past the end of the split is clamped to the split's last tile (PAGED16: to that tile's
+    // first position, t0 being a multiple of 16, so that the 16 rows read from the entry stay inside its page).
     auto load_index = [&](int n) -> int {
         int tok = t0 + (sub + n * WPH) * kTile + (PAGED16 ? 0 : c);
-        tok = min(tok, t1 - 1);
+        tok = min(tok, PAGED16 ? ((t1 - 1) & ~(kTile - 1)) : t1 - 1);
         return r2t_row[tok];
     };
     // Row addresses of the tile whose table entry is idx: K tokens 8t + o, V tokens 8t + 2j + b (instruction

@@ -69,6 +69,7 @@ class DeviceDecodeLoop:
         fp = self.mr.page_allocator.free_page
         self.free_pages[: fp.numel()].copy_(fp)
         self.free_range.copy_(torch.tensor([0, fp.numel()], dtype=torch.int32))
+        self._free_uploaded = fp.clone()
 
     # one step: prepare -> forward -> argmax -> log
     def _step(self):
@@ -126,6 +127,8 @@ class DeviceDecodeLoop:
         worst = self.bs * (-(-(self.pending + steps) // self.mr.page_size) + 1) if self.mr.page_size > 1 else self.bs * (self.pending + steps)
         if worst > free_now:
             raise RuntimeError(f"Not enough free pages available. need up to {worst}, free {free_now}")
+        if self.pending == 0 and not torch.equal(self._free_uploaded, self.mr.page_allocator.free_page):
+            self._upload_free_list()  # the host allocated or freed pages since (another batch's prefill, an eviction)
         self._set_metadata(self.pending + steps)
         for _ in range(steps):
             self.graph.replay()
@@ -138,9 +141,9 @@ class DeviceDecodeLoop:
             return [[] for _ in range(self.bs)]
         torch.cuda.synchronize()
         status = int(self.status.item())
-        if status != 0:
-            raise RuntimeError("device decode step refused: " + ("free list exhausted" if status == 1 else "context longer than the page table row"))
-        toks = self.token_log[:k].cpu().t().tolist()
+        # a refused step changes nothing and every later one is refused too: the accepted steps are a prefix
+        done = int(self.seq_lens[0].item()) - int(self.seq_lens_cpu[0]) if status != 0 else k
+        toks = self.token_log[:done].cpu().t().tolist() if done else [[] for _ in range(self.bs)]
         last = self.last_slots.cpu().tolist()
         b = self.batch
         for r, new, s in zip(b.reqs, toks, last):
@@ -155,4 +158,10 @@ class DeviceDecodeLoop:
         self.step_idx.zero_()
         self.pending = 0
         self._upload_free_list()                     # positions restart at 0 of what the host list now holds
+        if status != 0:
+            # the refused steps' forward passes left garbage there: the last accepted token is the next input again
+            self.next_tokens.copy_(torch.tensor([r.token_ids[-1] for r in b.reqs], dtype=torch.int32))
+            self.status.zero_()
+            raise RuntimeError(f"device decode step refused after {done} of {k} steps: "
+                               + ("free list exhausted" if status == 1 else "context longer than the page table row"))
         return toks

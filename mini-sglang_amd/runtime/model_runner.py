@@ -95,7 +95,6 @@ class ModelRunner:
         elif self.server_args.attention_backend == "hip":
             from ..attn.hip_attn_backend import HipAttnBackend
             self.attn_backend = HipAttnBackend(self)
-            self.attn_backend.graph_num_heads = self.model_config.num_heads // self.tp_size
             self.attn_backend.share_prefix_in_graphs = bool(self.server_args.share_prefix_in_graphs)
         else:
             raise ValueError(f"Unsupported attention backend: {self.server_args.attention_backend}")

@@ -168,6 +168,39 @@ def test_device_chained_decode_equals_host_prepared_steps(ps, lens):
         assert ra.token_ids == rc.token_ids
 
 
+def test_device_chained_decode_refusal_keeps_cache_and_host_state_consistent():
+    """A chained step the device free list cannot serve is refused as a whole and so is every step after it: the
+    forward passes of those steps write only the dummy slot, sync_host folds the accepted steps into the host state
+    before it raises, and decoding resumes from there with the same tokens as an undisturbed run."""
+    from mini_sglang_amd.runtime import decode_loop
+    from mini_sglang_amd.runtime.device_decode import DeviceDecodeLoop
+    from mini_sglang_amd.runtime.qwen3 import Qwen3Config
+
+    def build():
+        torch.manual_seed(1234)
+        cfg = Qwen3Config(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                          intermediate_size=512, vocab_size=2048, max_position_embeddings=4096, tie_word_embeddings=False)
+        return decode_loop.build_decode_state(cfg, 5, 0, 1, 64, use_graph=False, seed=3, seq_lens=[15, 16, 33, 200, 1])
+
+    steps = 20
+    mr_a, batch_a = build()
+    decode_loop.decode_steps(mr_a, batch_a, steps)
+    mr_b, batch_b = build()
+    loop = DeviceDecodeLoop(mr_b, batch_b, max_steps=32)
+    before = [len(r.token_ids) for r in batch_b.reqs]
+    # the device sees a free list that ends after three steps' worth of pages (page_size 1: five pages a step) plus two
+    loop.free_range[1] = 3 * 5 + 2
+    loop.run(8)
+    with pytest.raises(RuntimeError, match="refused after 3 of 8 steps"):
+        loop.sync_host()
+    assert [len(r.token_ids) - n for r, n in zip(batch_b.reqs, before)] == [3] * 5
+    loop.run(steps - 3)  # sync_host has brought the device free list back in line with the host allocator
+    loop.sync_host()
+    for ra, rb in zip(batch_a.reqs, batch_b.reqs):
+        assert ra.token_ids == rb.token_ids and ra.last_slot == rb.last_slot
+    assert torch.equal(mr_a.page_allocator.free_page, mr_b.page_allocator.free_page)
+
+
 @pytest.mark.parametrize("ps", [1, 16])
 def test_radix_cache_hit_generates_the_same_tokens(ps):
     """A second request that shares a prompt prefix with a finished one is prefilled on top of the cached slots

@@ -619,14 +619,19 @@ def test_prepare_decode_matches_oracle(bs, ps):
 def test_prepare_decode_refuses_as_a_whole():
     ops = _ops()
     d = lambda x: torch.tensor(x, dtype=torch.int32, device=DEV)
-    # three requests, two of them need a page, one page left: refused, nothing written
+    # three requests, two of them need a page, one page left: refused; lengths, table and free list untouched, and
+    # the step's K/V writes pointed at the dummy slot
     seq, rows, last = d([16, 5, 32]), d([0, 1, 2]), d([31, 100, 63])
     free, head, status = d([9, 4]), d([1, 2]), d([0])
     r2t = torch.full((3, 64), -1, dtype=torch.int32, device=DEV)
     pos, loc = d([-1, -1, -1]), d([-1, -1, -1])
     ops.prepare_decode(rows, seq, last, free, head, r2t, pos, loc, status, 16)
     assert status.item() == 1 and head.tolist() == [1, 2]
-    assert seq.tolist() == [16, 5, 32] and pos.tolist() == [-1] * 3 and loc.tolist() == [-1] * 3 and (r2t == -1).all()
+    assert seq.tolist() == [16, 5, 32] and pos.tolist() == [-1] * 3 and loc.tolist() == [0] * 3 and (r2t == -1).all()
+    assert last.tolist() == [31, 100, 63]
+    # sticky: a step the free list could serve is refused as well until the host has cleared the status word
+    ops.prepare_decode(rows, d([3, 5, 7]), last, free, head, r2t, pos, loc, status, 16)
+    assert status.item() == 1 and head.tolist() == [1, 2] and (r2t == -1).all()
     with pytest.raises(RuntimeError):
         orc.prepare_decode_ref([0, 1, 2], [16, 5, 32], [31, 100, 63], [9, 4], 1, torch.zeros((3, 64), dtype=torch.int32), 16)
     # a request that already fills its table row: refused with status 2
