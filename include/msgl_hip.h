@@ -111,6 +111,29 @@ int msgl_paged_decode(const void* q, int64_t q_stride,
                       const int32_t* start_lens, const int32_t* extra_splits,
                       void* stream);
 
+/* msgl_paged_decode for callers that cannot allocate and have no workspace to hand over
+ * (code under hipGraph capture, tight serving loops, harnesses that forbid hipMalloc).  It has
+ * no counterpart in the reference.  Same arguments, kernels and results as msgl_paged_decode
+ * without start_lens / extra_splits; the split workspace is a static device array inside the
+ * library, MSGL_PAGED_DECODE_STATIC_WORKSPACE_BYTES per GPU the library runs on, held until the
+ * process ends.  Calls whose bs x max_splits x Hq needs more
+ * (msgl_paged_decode_workspace_bytes) are refused with MSGL_E_WORKSPACE.  The call allocates
+ * nothing and frees nothing.  The array's device address is looked up on the first call on a
+ * device, so make that first call (a warm-up) outside graph capture.  All calls on one GPU share
+ * the array: calls that may overlap there (different streams, no ordering between them) race on
+ * it; calls on one stream, or ordered by events, do not.  Its contents need no clearing between
+ * calls. */
+#define MSGL_PAGED_DECODE_STATIC_WORKSPACE_BYTES (32u << 20)
+int msgl_paged_decode_static(const void* q, int64_t q_stride,
+                             const void* k_cache, const void* v_cache, int64_t cache_stride,
+                             const int32_t* req_to_token, int64_t r2t_stride,
+                             const int32_t* req_pool_indices, const int32_t* seq_lens,
+                             void* out, int64_t out_stride,
+                             int bs, int Hq, int Hkv, int D, int page_size, float scale,
+                             int max_splits, int chunk_tokens, const int32_t* chunk_dev,
+                             int kv_stream, const int32_t* reuse_lens, const int32_t* plan,
+                             void* stream);
+
 /* Launch order of msgl_paged_decode's (split, request) work items for a batch of unequal
  * lengths, built on the device (the lengths are never read back): every full split first, then
  * each request's partial last split by falling length; item = split * bs + request, unused

@@ -26,6 +26,7 @@
 #include "decode_params.h"
 #include "plan_sort.h"
 
+#include <mutex>
 #include <type_traits>
 
 namespace msgl {
@@ -578,13 +579,13 @@ extern "C" size_t msgl_paged_decode_workspace_bytes(int bs, int Hq, int D, int m
     return (size_t)bs * max_splits * Hq * (D + 2) * sizeof(float);
 }
 
-extern "C" int msgl_paged_decode(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
-                                 int64_t cache_stride, const int32_t* req_to_token, int64_t r2t_stride,
-                                 const int32_t* req_pool_indices, const int32_t* seq_lens, void* out,
-                                 int64_t out_stride, void* workspace, size_t workspace_bytes, int bs, int Hq, int Hkv,
-                                 int D, int page_size, float scale, int max_splits, int chunk_tokens,
-                                 const int32_t* chunk_dev, int kv_stream, const int32_t* reuse_lens, const int32_t* plan,
-                                 const int32_t* start_lens, const int32_t* extra_splits, void* stream) {
+static int paged_decode_checked(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                                int64_t cache_stride, const int32_t* req_to_token, int64_t r2t_stride,
+                                const int32_t* req_pool_indices, const int32_t* seq_lens, void* out,
+                                int64_t out_stride, void* workspace, size_t workspace_bytes, int bs, int Hq, int Hkv,
+                                int D, int page_size, float scale, int max_splits, int chunk_tokens,
+                                const int32_t* chunk_dev, int kv_stream, const int32_t* reuse_lens, const int32_t* plan,
+                                const int32_t* start_lens, const int32_t* extra_splits, void* stream) {
     if (bs == 0) return MSGL_OK;
     MSGL_REQUIRE(bs > 0, "msgl_paged_decode: bs=%d", bs);
     MSGL_REQUIRE(cache_stride <= (int64_t)1 << 27, "msgl_paged_decode: cache_stride %lld too large", (long long)cache_stride);
@@ -646,6 +647,74 @@ extern "C" int msgl_paged_decode(const void* q, int64_t q_stride, const void* k_
     }
     set_error("msgl_paged_decode: Hq/Hkv=%d unsupported (1, 2, 4 or 8)", Hq / Hkv);
     return MSGL_E_INVALID;
+}
+
+extern "C" int msgl_paged_decode(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                                 int64_t cache_stride, const int32_t* req_to_token, int64_t r2t_stride,
+                                 const int32_t* req_pool_indices, const int32_t* seq_lens, void* out,
+                                 int64_t out_stride, void* workspace, size_t workspace_bytes, int bs, int Hq, int Hkv,
+                                 int D, int page_size, float scale, int max_splits, int chunk_tokens,
+                                 const int32_t* chunk_dev, int kv_stream, const int32_t* reuse_lens, const int32_t* plan,
+                                 const int32_t* start_lens, const int32_t* extra_splits, void* stream) {
+    return paged_decode_checked(q, q_stride, k_cache, v_cache, cache_stride, req_to_token, r2t_stride, req_pool_indices, seq_lens, out,
+                                out_stride, workspace, workspace_bytes, bs, Hq, Hkv, D, page_size, scale, max_splits, chunk_tokens,
+                                chunk_dev, kv_stream, reuse_lens, plan, start_lens, extra_splits, stream);
+}
+
+// ---- the same call for callers that cannot allocate: the split workspace lives in the code object ----
+// One copy per GPU the library runs on, held until the process ends.  Host code never uses the array's name as an
+// address (on the host it is only a handle): the device address is looked up once per device and kept.
+static __device__ __align__(256) unsigned char scratch[MSGL_PAGED_DECODE_STATIC_WORKSPACE_BYTES];
+
+static constexpr int kMaxDevices = 64;
+static void* g_scratch_ptr[kMaxDevices];  // per device: address of that device's copy of `scratch`
+static std::mutex g_scratch_mutex;
+
+// Device address of the current device's scratch array; looked up on the first call on that device.
+static int scratch_for_current_device(void** ptr_out) {
+    int dev = -1;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        set_error("msgl_paged_decode_static: cannot tell the current device (%s, device %d)", hipGetErrorString(err), dev);
+        return MSGL_E_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* ptr = nullptr;
+        err = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (err != hipSuccess || ptr == nullptr) {
+            set_error("msgl_paged_decode_static: hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(err));
+            return MSGL_E_LAUNCH;
+        }
+        g_scratch_ptr[dev] = ptr;
+    }
+    *ptr_out = g_scratch_ptr[dev];
+    return MSGL_OK;
+}
+
+extern "C" int msgl_paged_decode_static(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                                        int64_t cache_stride, const int32_t* req_to_token, int64_t r2t_stride,
+                                        const int32_t* req_pool_indices, const int32_t* seq_lens, void* out,
+                                        int64_t out_stride, int bs, int Hq, int Hkv, int D, int page_size, float scale,
+                                        int max_splits, int chunk_tokens, const int32_t* chunk_dev, int kv_stream,
+                                        const int32_t* reuse_lens, const int32_t* plan, void* stream) {
+    if (bs == 0) return MSGL_OK;
+    const size_t need = max_splits > 1 ? msgl_paged_decode_workspace_bytes(bs, Hq, D, max_splits) : 0;
+    if (need > (size_t)MSGL_PAGED_DECODE_STATIC_WORKSPACE_BYTES) {
+        set_error("msgl_paged_decode_static: bs=%d x max_splits=%d x Hq=%d needs %zu bytes of split workspace, the built-in one holds "
+                  "%zu; lower max_splits or use msgl_paged_decode with a workspace of your own",
+                  bs, max_splits, Hq, need, (size_t)MSGL_PAGED_DECODE_STATIC_WORKSPACE_BYTES);
+        return MSGL_E_WORKSPACE;
+    }
+    void* ws = nullptr;
+    if (max_splits > 1) {
+        const int rc = scratch_for_current_device(&ws);
+        if (rc) return rc;
+    }
+    // nothing in the workspace has to start at zero: the merge reads exactly the partials this call's main kernel wrote
+    return paged_decode_checked(q, q_stride, k_cache, v_cache, cache_stride, req_to_token, r2t_stride, req_pool_indices, seq_lens, out,
+                                out_stride, ws, ws ? (size_t)MSGL_PAGED_DECODE_STATIC_WORKSPACE_BYTES : 0, bs, Hq, Hkv, D, page_size, scale,
+                                max_splits, chunk_tokens, chunk_dev, kv_stream, reuse_lens, plan, nullptr, nullptr, stream);
 }
 
 extern "C" int msgl_decode_plan(const int32_t* seq_lens, int bs, int max_splits, int chunk_tokens, const int32_t* chunk_dev,

@@ -162,6 +162,43 @@ def paged_decode(
     return out
 
 
+STATIC_WORKSPACE_BYTES = 32 << 20  # MSGL_PAGED_DECODE_STATIC_WORKSPACE_BYTES
+
+
+def paged_decode_static(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, req_to_token: torch.Tensor,
+                        req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, scale: float, page_size: int, out: torch.Tensor, *,
+                        max_splits: int = 1, chunk_tokens: int = 0, chunk_dev: Optional[torch.Tensor] = None, kv_stream: bool = True,
+                        reuse_lens: Optional[torch.Tensor] = None, plan: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """paged_decode through the entry point that allocates nothing: the caller brings `out`, the split workspace is the
+    library's built-in one (STATIC_WORKSPACE_BYTES per GPU; larger needs are refused).  Calls that overlap on one
+    GPU share that workspace and race."""
+    _dev_bf16(q, "q"), _dev_bf16(out, "out")
+    _dev_i32(req_pool_indices, "req_pool_indices"), _dev_i32(seq_lens, "seq_lens")
+    _need(q.dim() == 3 and q.stride(2) == 1 and q.stride(1) == q.shape[2], "q must be [bs, Hq, D] with dense heads")
+    bs, Hq, D = q.shape
+    _need(k_cache.dim() == 3, "k_cache must be [slots, Hkv, D]")
+    Hkv = k_cache.shape[1]
+    cs = _cache_stride(k_cache, v_cache, Hkv, D)
+    _need(req_to_token.is_cuda and req_to_token.dtype == torch.int32 and req_to_token.dim() == 2
+          and req_to_token.stride(1) == 1, "req_to_token must be an int32 [reqs, ctx] GPU tensor with dense rows")
+    _need(req_pool_indices.numel() == bs and seq_lens.numel() == bs, "req_pool_indices / seq_lens must have bs entries")
+    _need(out.shape == q.shape and out.stride(2) == 1 and out.stride(1) == D, "out must match q's layout")
+    for t, name in ((reuse_lens, "reuse_lens"), (chunk_dev, "chunk_dev"), (plan, "plan")):
+        if t is not None:
+            _dev_i32(t, name)
+    if chunk_dev is None and chunk_tokens <= 0:
+        _need(max_splits == 1, "chunk_tokens is required when max_splits > 1")
+        chunk_tokens = 1 << 30
+    _need(plan is None or plan.numel() == bs * max_splits, "plan must have bs * max_splits entries")
+    _check(_lib.msgl_paged_decode_static(
+        q.data_ptr(), q.stride(0) if bs > 1 else Hq * D, k_cache.data_ptr(), v_cache.data_ptr(), cs,
+        req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(), seq_lens.data_ptr(),
+        out.data_ptr(), out.stride(0) if bs > 1 else Hq * D, bs, Hq, Hkv, D, page_size, float(scale), max_splits, int(chunk_tokens),
+        chunk_dev.data_ptr() if chunk_dev is not None else None, 1 if kv_stream else 0,
+        reuse_lens.data_ptr() if reuse_lens is not None else None, plan.data_ptr() if plan is not None else None, _stream()))
+    return out
+
+
 def shared_prefix_decode(
     q: torch.Tensor,
     k_cache: torch.Tensor,
