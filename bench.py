@@ -28,6 +28,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+RANKS_PER_DEVICE = 1    # set in main(): > 1 only when ranks share a GPU (rehearsal)
+
+
+def trace(msg):
+    """Progress line on stderr (MSGL_BENCH_TRACE=1): where a long run is, with seconds since start."""
+    if os.environ.get("MSGL_BENCH_TRACE"):
+        print(f"[bench {time.perf_counter() - _T0:7.1f}s rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
 
 
 def parse():
@@ -55,6 +65,7 @@ def parse():
     ap.add_argument("--e2e-ctx", type=int, default=0, help="0 = 8192 if the whole-model KV fits in HBM, else the largest power of two that does")
     ap.add_argument("--e2e-steps", type=int, default=16)
     ap.add_argument("--e2e-eager", action="store_true", help="do not capture decode steps in hipGraphs")
+    ap.add_argument("--mixed-bs", type=int, default=256, help="largest batch the mixed-length whole-model measurement tries")
     ap.add_argument("--allreduce-trial-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend under N > 1 (gloo: ranks may share a GPU, for rehearsals)")
     return ap.parse_args()
@@ -62,6 +73,10 @@ def parse():
 
 def main():
     args = parse()
+    if os.environ.get("MSGL_BENCH_TRACE"):  # a run that stops making progress says where, every two minutes
+        import faulthandler
+
+        faulthandler.dump_traceback_later(120, repeat=True, file=sys.stderr)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -131,27 +146,31 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # HIP events on the launch stream (torch's current stream) around every timed step: the per-launch device time is
+    # the MEDIAN of the K intervals; `value` stays the wall clock over exactly K steps between two barriers
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    ev0.record()
+    evs[0].record()
     for i in range(args.steps):
         step(i)
-    ev1.record()
+        evs[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream)
+    per_step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    dev_ms_median = per_step_ms[len(per_step_ms) // 2] if len(per_step_ms) % 2 else 0.5 * (per_step_ms[len(per_step_ms) // 2 - 1] + per_step_ms[len(per_step_ms) // 2])
+    dev_ms_mean = evs[0].elapsed_time(evs[-1]) / args.steps
     if world > 1:
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(t[0]), float(t[1])
+        from mini_sglang_amd.comm import agree
+
+        elapsed, dev_ms_median, dev_ms_mean = (agree(v, "max", dev) for v in (elapsed, dev_ms_median, dev_ms_mean))
 
     bytes_per_step_rank = 2 * Hkv * D * 2 * S * bs
     total_bytes = bytes_per_step_rank * world * args.steps
     value = total_bytes / elapsed / 1e9
-    launch_ms = dev_ms / args.steps
-    achieved = bytes_per_step_rank / (launch_ms * 1e-3) / 1e9  # per GPU, device time per launch
+    launch_ms = dev_ms_median
+    achieved = bytes_per_step_rank / (launch_ms * 1e-3) / 1e9  # per GPU, median device time per launch
 
     result = {
         "metric": "paged_decode_attention_hbm_bandwidth",
@@ -181,36 +200,41 @@ def main():
             "traffic": None,
             "kernel": "paged_decode_kernel (+ split merge)",
             "launch_ms": round(launch_ms, 4),
+            "launch_ms_stat": f"median of {args.steps} HIP-event intervals on the launch stream",
+            "launch_ms_mean": round(dev_ms_mean, 4),
+            "launch_ms_min_max": [round(per_step_ms[0], 4), round(per_step_ms[-1], 4)],
             "bytes_per_launch": bytes_per_step_rank,
         },
     }
 
-    # an on-box yardstick beside the spec peak: a large device-to-device copy (reads + writes both counted)
+    # an on-box yardstick beside the spec peak: this library's read-only stream kernel (16 B per lane, non-temporal,
+    # nothing stored) over the first layer's pool, which is far larger than the caches
     try:
-        src = torch.empty(1 << 31, dtype=torch.uint8, device=dev)
-        dst = torch.empty_like(src)
+        buf = pools[0][0] if args.layout == "split" else pools[0][0]._base
+        buf = buf.view(-1)
+        sink = torch.zeros(64, dtype=torch.int32, device=dev)
         for _ in range(2):
-            dst.copy_(src)
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        c0.record()
-        for _ in range(5):
-            dst.copy_(src)
-        c1.record()
+            ops.stream_read(buf, sink)
+        c = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        c[0].record()
+        for i in range(5):
+            ops.stream_read(buf, sink)
+            c[i + 1].record()
         torch.cuda.synchronize()
-        copy_gbps = 2 * src.numel() * 5 / (c0.elapsed_time(c1) * 1e-3) / 1e9
-        result["roofline"]["measured_copy_GBps"] = round(copy_gbps, 1)
-        result["roofline"]["frac_of_measured_copy"] = round(achieved / copy_gbps, 4)
-        del src, dst
+        ts = sorted(c[i].elapsed_time(c[i + 1]) for i in range(5))
+        read_gbps = buf.numel() * buf.element_size() / (ts[2] * 1e-3) / 1e9
+        result["roofline"]["measured_stream_read_GBps"] = round(read_gbps, 1)
+        result["roofline"]["stream_read_bytes"] = buf.numel() * buf.element_size()
+        result["roofline"]["frac_of_measured_stream_read"] = round(achieved / read_gbps, 4)
     except Exception as e:
-        result["roofline"]["measured_copy_error"] = f"{type(e).__name__}: {e}"[:120]
+        result["roofline"]["measured_stream_read_error"] = f"{type(e).__name__}: {e}"[:120]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(pools[0], qs[0], r2t, S, ps, Hq, Hkv, D, scale, args.cpu_seconds)
-    if args.layout == "interleaved" and bs == 256 and S == 8192 and ps == 16 and Hq == 32 and Hkv == 8:
-        # HBM bytes per launch from rocprofv3 PMC passes of this exact shape (profiles/r01_decode_bs256_ctx8192.md):
-        # 2 x FETCH_SIZE (gfx950 reports half of a wide coalesced read stream) + WRITE_SIZE
-        result["roofline"]["traffic"] = 8.62e9
-        result["roofline"]["traffic_source"] = "profiles/r01_decode_bs256_ctx8192.md"
+    # HBM bytes per launch of this exact shape from rocprofv3 PMC passes, as scripts/pmc_decode.sh collected them and
+    # scripts/pmc_traffic.py reduced them to profiles/decode_traffic.json (the corrections the counters need on gfx950
+    # are applied there and named in the file); null for any other shape or when the file is absent
+    result["roofline"].update(recorded_traffic(args.layout, bs, S, ps, Hq, Hkv))
     del pools, qs, ws, out
     torch.cuda.empty_cache()
     # The secondary measurements below must never cost the headline line: if one of them is still running
@@ -231,35 +255,57 @@ def main():
     watchdog = threading.Timer(args.secondary_deadline, give_up)
     watchdog.daemon = True
     watchdog.start()
+    trace("headline done")
     if not args.no_configs:
         result["other_configs"] = other_decode_configs(args, world, rank)
+        trace("other_configs done")
     if not args.no_extend:
         result["extend"] = extend_attention(args, world, rank)
+        trace("extend done")
     xgmi_ok = False
+    # ranks per physical GPU: 1 on a node with a GPU per rank, more in a one-GPU rehearsal, where every rank must
+    # size its pools for its share of the memory it sees free
+    global RANKS_PER_DEVICE
+    RANKS_PER_DEVICE = max(1, -(-world // max(1, torch.cuda.device_count())))
     if world > 1 and not args.no_e2e:
         result["tp_allreduce"] = tp_allreduce_trial_isolated(world, rank, local_rank, barrier)
         xgmi_ok = bool(result["tp_allreduce"].get("validated"))
-    if world > 1 and args.dist_backend != "nccl" and not args.no_e2e:
-        # rehearsal on a CPU-side backend: it can neither be captured in a graph nor reduce bf16 tensors on the GPU
-        result["decode_e2e"] = {"skipped": f"whole-model decode needs the nccl backend, not {args.dist_backend}"}
-        args.no_e2e = True
+        trace(f"all-reduce trial done, validated={xgmi_ok}")
+    rehearsal = world > 1 and args.dist_backend != "nccl"
+    if rehearsal and not args.no_e2e:
+        # A CPU-side backend (gloo) can neither be captured in a graph nor reduce bf16 tensors on the GPU: the
+        # whole-model legs then run eagerly with every hidden-state all-reduce on the direct-read kernels (issued
+        # step by step when the ranks share a device).  Same control flow as the RCCL run; the times mean nothing.
+        if xgmi_ok:
+            from mini_sglang_amd import comm
+
+            args.e2e_eager = True
+            comm.enable_xgmi_allreduce()
+            result["rehearsal"] = f"{args.dist_backend} backend, eager steps, all-reduce on direct peer reads, {RANKS_PER_DEVICE} rank(s) per GPU"
+        else:
+            result["decode_e2e"] = {"skipped": f"whole-model decode under {args.dist_backend} needs the direct-read all-reduce, which did not validate"}
+            args.no_e2e = True
     if not args.no_e2e:
         result["decode_e2e"] = decode_e2e(args, world, rank, barrier)
+        trace("decode_e2e done")
         import gc
 
         gc.collect()
         torch.cuda.empty_cache()
         result["decode_e2e_mixed"] = decode_e2e_mixed(args, world, rank, barrier)
+        trace("decode_e2e_mixed done")
         if world == 1:
             gc.collect()
             torch.cuda.empty_cache()
             result["decode_e2e_small"] = decode_e2e_small(args, barrier)
-        if xgmi_ok:  # the same steps with the o_proj / down_proj / embedding all-reduces on direct peer reads
+        if rehearsal:
+            from mini_sglang_amd import comm
+
+            comm.disable_xgmi_allreduce()
+        elif xgmi_ok:  # the same steps with the o_proj / down_proj / embedding all-reduces on direct peer reads
             from mini_sglang_amd import comm
 
             try:
-                import gc
-
                 gc.collect()
                 torch.cuda.empty_cache()
                 comm.enable_xgmi_allreduce()
@@ -274,6 +320,20 @@ def main():
         import torch.distributed as dist
 
         dist.destroy_process_group()
+
+
+def recorded_traffic(layout, bs, S, ps, Hq, Hkv):
+    path = os.path.join(ROOT, "profiles", "decode_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return {"traffic": None}
+    shape = rec.get("shape", {})
+    if shape != {"layout": layout, "batch": bs, "ctx": S, "page_size": ps, "hq": Hq, "hkv": Hkv}:
+        return {"traffic": None}
+    return {"traffic": rec.get("traffic_bytes_per_launch"), "traffic_source": "profiles/decode_traffic.json: " + rec.get("how", ""),
+            "traffic_measured_at_commit": rec.get("commit")}
 
 
 def other_decode_configs(args, world, rank):
@@ -455,14 +515,15 @@ def decode_e2e_mixed(args, world, rank, barrier):
         cfg = Qwen3Config.qwen3_8b()
         ps = 16
         free, _ = torch.cuda.mem_get_info()
+        free //= RANKS_PER_DEVICE
         if world > 1:  # every rank must build the same batch: size it for the rank with the least free memory
             import torch.distributed as dist
 
-            f = torch.tensor([free], dtype=torch.int64, device="cuda")
-            dist.all_reduce(f, op=dist.ReduceOp.MIN)
-            free = int(f[0])
+            from mini_sglang_amd.comm import agree
+
+            free = int(agree(float(free), "min", "cuda"))
         per_token = 2 * (cfg.num_key_value_heads // world) * cfg.head_dim * 2 * cfg.num_hidden_layers
-        bs = 256
+        bs = max(16, args.mixed_bs)
         while True:
             lens = workload.mixed_lengths(bs, 1024, 32768, 3)
             groups = [i // 16 for i in range(bs)]
@@ -486,9 +547,9 @@ def decode_e2e_mixed(args, world, rank, barrier):
             if world > 1:
                 import torch.distributed as dist
 
-                t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt = float(t[0])
+                from mini_sglang_amd.comm import agree
+
+                dt = agree(dt, "max", "cuda")
             info["tok_per_s" + suffix] = round(bs * steps / dt, 1)
             info["ms_per_step" + suffix] = round(dt / steps * 1e3, 3)
             del mr, batch
@@ -510,6 +571,7 @@ def decode_e2e(args, world, rank, barrier):
         cfg = Qwen3Config.qwen3_8b()
         bs, ps = args.bs, args.page_size
         free, total = torch.cuda.mem_get_info()
+        free //= RANKS_PER_DEVICE
         weights = 2 * 8.2e9 / world
         per_token = 2 * (cfg.num_key_value_heads // world) * cfg.head_dim * 2 * cfg.num_hidden_layers
         ctx = args.e2e_ctx
@@ -520,9 +582,9 @@ def decode_e2e(args, world, rank, barrier):
             if world > 1:  # every rank must build the same page tables: agree on the smallest choice
                 import torch.distributed as dist
 
-                c = torch.tensor([ctx], dtype=torch.int64, device="cuda")
-                dist.all_reduce(c, op=dist.ReduceOp.MIN)
-                ctx = int(c[0])
+                from mini_sglang_amd.comm import agree
+
+                ctx = int(agree(float(ctx), "min", "cuda"))
         info = {"model": "Qwen3-8B shape, random weights", "batch": bs, "ctx": ctx, "page_size": ps, "tp": world}
         use_graph = not args.e2e_eager
         try:
@@ -538,18 +600,16 @@ def decode_e2e(args, world, rank, barrier):
         if world > 1:
             import torch.distributed as dist  # noqa: F811
 
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t[0])
+            from mini_sglang_amd.comm import agree
+
+            dt = agree(dt, "max", "cuda")
         info.update({"tok_per_s": round(bs * args.e2e_steps / dt, 1), "ms_per_step": round(dt / args.e2e_steps * 1e3, 3),
                      "steps": args.e2e_steps, "hip_graph": use_graph})
         if use_graph:
             try:  # the same steps chained on the device, 8 per host synchronisation
                 dt = decode_loop.time_decode_chained(mr, batch, args.e2e_steps, 2, chain=8, barrier=barrier)
                 if world > 1:
-                    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    dt = float(t[0])
+                    dt = agree(dt, "max", "cuda")
                 info.update({"tok_per_s_chained": round(bs * args.e2e_steps / dt, 1),
                              "ms_per_step_chained": round(dt / args.e2e_steps * 1e3, 3), "chain": 8})
             except Exception as e:
@@ -596,9 +656,9 @@ def tp_allreduce_trial_isolated(world, rank, local_rank, barrier):
     except Exception as e:  # noqa: BLE001 (timeout included: subprocess.run has killed the child)
         info["error"] = f"{type(e).__name__}: {e}"[:300]
     dev = torch.device("cuda", torch.cuda.current_device())
-    flag = torch.tensor([1 if info.get("validated") else 0], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    info["validated"] = bool(int(flag[0]))
+    from mini_sglang_amd.comm import agree
+
+    info["validated"] = bool(agree(1.0 if info.get("validated") else 0.0, "min", dev))
     info["isolated"] = True
     if info["validated"] and "sizes" in info and dist.get_backend() == "nccl":  # RCCL on the same sizes, in this process
         for name, entry in info["sizes"].items():
@@ -612,9 +672,7 @@ def tp_allreduce_trial_isolated(world, rank, local_rank, barrier):
                 dist.all_reduce(x)
             e1.record()
             torch.cuda.synchronize()
-            t = torch.tensor([e0.elapsed_time(e1) * 10.0], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            entry["rccl_us"] = round(float(t[0]), 2)
+            entry["rccl_us"] = round(agree(e0.elapsed_time(e1) * 10.0, "max", dev), 2)
     return info
 
 
@@ -624,7 +682,7 @@ def tp_allreduce_trial(world, rank, barrier):
     result equals the fp32 rank-order sum of the gathered inputs bit for bit and no kernel timed out."""
     import torch.distributed as dist
 
-    from mini_sglang_amd.comm import XgmiAllReduce
+    from mini_sglang_amd.comm import XgmiAllReduce, agree, tp_all_gather
 
     info = {"validated": False}
     try:
@@ -637,8 +695,7 @@ def tp_allreduce_trial(world, rank, barrier):
         for n in (4096, 64 * 4096, 256 * 4096):  # torch collectives first ...
             g = torch.Generator(device=dev).manual_seed(17 * n + rank)
             x = torch.randn(n, device=dev, generator=g).bfloat16()
-            parts = [torch.empty_like(x) for _ in range(world)]
-            dist.all_gather(parts, x)
+            parts = tp_all_gather(x)
             want = torch.zeros(n, dtype=torch.float32, device=dev)
             for p in parts:
                 want += p.float()
@@ -652,9 +709,7 @@ def tp_allreduce_trial(world, rank, barrier):
         except Exception as e:  # noqa: BLE001
             ok = False
             info["error"] = f"{type(e).__name__}: {e}"[:300]
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        info["validated"] = bool(int(flag[0]))
+        info["validated"] = bool(agree(1.0 if ok else 0.0, "min", dev))
         if not info["validated"]:
             return info
 
@@ -668,9 +723,7 @@ def tp_allreduce_trial(world, rank, barrier):
                 fn(x)
             e1.record()
             torch.cuda.synchronize()
-            t = torch.tensor([e0.elapsed_time(e1) / iters * 1e3], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return round(float(t[0]), 2)
+            return round(agree(e0.elapsed_time(e1) / iters * 1e3, "max", dev), 2)
 
         sizes = {}
         for bs in (1, 16, 64, 256):
@@ -693,7 +746,11 @@ def cpu_baseline(pool, q, r2t, S, ps, Hq, Hkv, D, scale, budget_s):
     K/V rows copied to host memory at scattered slots."""
     from oracle import torch_oracle as orc
 
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    # threads: the CPUs this process may run on (its affinity mask), further limited by OMP_NUM_THREADS when the box
+    # sets one (a GPU box hands a job a share of the machine, not all of os.cpu_count()); both numbers are reported
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    cores = max(1, min(allowed, omp) if omp > 0 else allowed)
     torch.set_num_threads(cores)
     kc, vc = pool
 
@@ -736,7 +793,8 @@ def cpu_baseline(pool, q, r2t, S, ps, Hq, Hkv, D, scale, budget_s):
     gbps = 2 * Hkv * D * 2 * S * n * reps / dt / 1e9
     return {"value": round(gbps, 3), "unit": "GB/s", "cores": cores, "kind": "port",
             "sample": f"first {n} of the batch's {q.shape[0]} requests ({S} tokens each), one layer, {reps} passes, {dt:.1f} s of host time",
-            "cpu_model": _cpu_model()}
+            "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(), "cpus_allowed": allowed,
+            "threads_note": "threads = min(CPUs in this process's affinity mask, OMP_NUM_THREADS if the box sets it)"}
 
 
 def _cpu_model():

@@ -318,6 +318,14 @@ int msgl_prepare_decode(const int32_t* req_pool_indices, int32_t* seq_lens, int3
                         const int32_t* next_tokens, int32_t* input_ids,
                         int32_t* status, int bs, int page_size, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Measurement utility (no counterpart in the reference): reads `bytes` bytes at src
+ * once, 16 bytes per lane with the non-temporal hint, and stores nothing (sink: 256
+ * bytes of device memory that are practically never written).  bench.py times it as
+ * the on-box read-only streaming rate beside the decode kernel's.
+ * ------------------------------------------------------------------------- */
+int msgl_stream_read(const void* src, size_t bytes, void* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,9 +152,48 @@ def disable_xgmi_allreduce() -> None:
         _active = None
 
 
+def _host_side_backend(group=None) -> bool:
+    """True when the process group runs on the CPU (gloo): GPU tensors then cross it as host copies made HERE, with
+    plain synchronous device<->host copies, instead of through the backend's own staging streams and events (two
+    processes sharing one GPU in a rehearsal were seen to stall there)."""
+    return dist.get_backend(group) != "nccl"
+
+
 def tp_all_reduce(t: torch.Tensor) -> torch.Tensor:
     """The all-reduce of the tensor-parallel linears (linear.py:246-247), in place."""
     if _active is not None and _active.fits(t):
         return _active.all_reduce(t)
+    if t.is_cuda and _host_side_backend():
+        h = t.float().cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+        return t
     dist.all_reduce(t)
     return t
+
+
+def tp_all_gather(t: torch.Tensor, group=None):
+    """Every rank's `t` (equal shapes), in rank order (logits_processor.py:61-64).  A gather only copies, so the
+    tensors travel as bytes, whatever the backend can reduce."""
+    world = dist.get_world_size(group)
+    if t.is_cuda and _host_side_backend(group):
+        h = t.contiguous().view(torch.uint8).cpu()
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h, group=group)
+        return [p.to(t.device).view(t.dtype).view(t.shape) for p in parts]
+    t = t.contiguous()
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather([p.view(torch.uint8) for p in parts], t.view(torch.uint8), group=group)
+    return parts
+
+
+def agree(value: float, op: str = "max", device=None) -> float:
+    """One number every rank ends up with: the max / min over the ranks' values (control decisions and timings)."""
+    red = dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.MIN
+    if device is None or _host_side_backend():
+        t = torch.tensor([value], dtype=torch.float64)
+        dist.all_reduce(t, op=red)
+        return float(t[0])
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=red)
+    return float(t[0])

@@ -543,3 +543,9 @@ def prepare_decode(req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, last_
         free_range.data_ptr(), req_to_token.data_ptr(), req_to_token.stride(0), req_to_token.shape[1], positions.data_ptr(),
         out_cache_loc.data_ptr(), next_tokens.data_ptr() if next_tokens is not None else None,
         input_ids.data_ptr() if input_ids is not None else None, status.data_ptr(), bs, page_size, _stream()))
+
+
+def stream_read(buf: torch.Tensor, sink: torch.Tensor) -> None:
+    """Read every byte of `buf` once (16 B per lane, non-temporal) and store nothing: the benchmark's yardstick."""
+    _need(buf.is_cuda and buf.is_contiguous() and sink.is_cuda and sink.numel() * sink.element_size() >= 256, "GPU buffers expected")
+    _check(_lib.msgl_stream_read(buf.data_ptr(), buf.numel() * buf.element_size() // 16 * 16, sink.data_ptr(), _stream()))

@@ -21,7 +21,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 from torch import nn
 
-from ..comm import tp_all_reduce
+from ..comm import tp_all_gather, tp_all_reduce
 
 
 @dataclasses.dataclass
@@ -37,6 +37,9 @@ class Qwen3Config:
     rope_theta: float = 1000000.0
     rms_norm_eps: float = 1e-6
     tie_word_embeddings: bool = True
+    # synthetic-weight knob, not part of the architecture: std of a random (untied, non-successor) lm_head; None = the
+    # std of the other matrices
+    lm_head_std: Optional[float] = None
 
     @staticmethod
     def qwen3_0_6b(**kw):
@@ -184,10 +187,7 @@ class Qwen3ForCausalLM(nn.Module):
         logits = F.linear(self.forward_hidden(input_ids, positions, batch), self.lm_head)
         _, tp = _tp()
         if tp > 1:
-            parts = [torch.empty_like(logits) for _ in range(tp)]
-            # a gather only copies: as bytes it runs on every backend, whatever that backend can reduce
-            dist.all_gather([p.view(torch.uint8) for p in parts], logits.view(torch.uint8))
-            logits = torch.cat(parts, dim=-1)
+            logits = torch.cat(tp_all_gather(logits), dim=-1)
         return logits
 
     def forward_greedy(self, input_ids: torch.Tensor, positions: torch.Tensor, batch, argmax_fn, out: Optional[torch.Tensor] = None):
@@ -213,9 +213,7 @@ def pick_sharded_argmax(idx: torch.Tensor, val: torch.Tensor, vocab_per_rank: in
     if tp == 1:
         return idx
     pair = torch.stack([val, idx.view(torch.float32)], dim=-1)   # index bits travel unchanged in an fp32 slot
-    parts = [torch.empty_like(pair) for _ in range(tp)]
-    dist.all_gather(parts, pair)
-    allp = torch.stack(parts)                                    # [tp, bs, 2]
+    allp = torch.stack(tp_all_gather(pair))                      # [tp, bs, 2]
     win = torch.argmax(allp[..., 0], dim=0, keepdim=True)        # [1, bs]
     local = allp[..., 1].contiguous().view(torch.int32).gather(0, win)[0]
     return local + (win[0] * vocab_per_rank).to(torch.int32)
@@ -254,7 +252,8 @@ def init_weights(model: Qwen3ForCausalLM, seed: int, std: float = 0.02, embed_st
         emb = full((cfg.vocab_size, hid), 1, embed_std if embed_std is not None else std)
         model.embed_tokens.copy_(rows(emb, cfg.vocab_size).to(dt))
         if not cfg.tie_word_embeddings:
-            head = torch.roll(emb, shifts=1, dims=0) * successor_head if successor_head > 0 else full((cfg.vocab_size, hid), 2)
+            head = torch.roll(emb, shifts=1, dims=0) * successor_head if successor_head > 0 else full(
+                (cfg.vocab_size, hid), 2, cfg.lm_head_std if cfg.lm_head_std is not None else std)
             model.lm_head.copy_(rows(head, cfg.vocab_size).to(dt))
         elif successor_head > 0:
             raise ValueError("successor_head needs an untied lm_head (tie_word_embeddings=False)")

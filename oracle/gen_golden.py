@@ -190,7 +190,19 @@ E2E_CASES = {
                        vocab_size=2048, max_position_embeddings=1024, tie_word_embeddings=False), 16, (42, [15, 16, 33]), 64, 8, 0.02, 0.3, 0.04),
     # first configuration of the benchmark family: Qwen3-0.6B shape, page_size 1, 256 greedy tokens, batch 2 (about 6 minutes of host time)
     "qwen3_0.6b_ps1": (dict(max_position_embeddings=2048, tie_word_embeddings=False), 1, (43, [16, 29]), 256, 11, 0.01, 0.3, 0.02),
+    # the same shape with a RANDOM head (no successor structure): top-2 margins of a bf16 ulp occur, so two correct
+    # implementations need not agree on the stream; compared teacher-forced (the fixture's tokens are fed back) on the
+    # logits of all 256 steps
+    "qwen3_0.6b_ps1_random_head": (dict(max_position_embeddings=2048, tie_word_embeddings=False, lm_head_std=0.005), 1, (47, [23, 9]), 256, 13,
+                                   0.01, 0.3, 0.0),
 }
+WIDE_COLS = 2048
+
+
+def wide_slice(logits: torch.Tensor) -> torch.Tensor:
+    """WIDE_COLS columns spread evenly over the vocabulary (every column when the vocabulary is that small)."""
+    stride = max(1, logits.shape[-1] // WIDE_COLS)
+    return logits[:, ::stride][:, :WIDE_COLS]
 
 
 def e2e_prompts(seed: int, lengths, vocab: int):
@@ -261,9 +273,10 @@ def gen_e2e(out_dir: str, name: str, spec):
     sp = SamplingParams(temperature=0.0, max_new_tokens=new_tokens + 8, ignore_eos=True)
     reqs = [Req(str(i), p, sp) for i, p in enumerate(prompts)]
     batch = BatchInfo.init_new(reqs=reqs, req_to_token_pool=r2t, page_allocator=pa, kv_cache_pool=kv)
-    margins, tops, slices, locs = [], [], [], []
+    margins, tops, slices, locs, wide = [], [], [], [], []
 
     def record(logits):
+        wide.append(wide_slice(logits.next_token_logits).clone())
         lf = logits.next_token_logits.float()
         top2 = lf.topk(2, dim=-1).values
         margins.append((top2[:, 0] - top2[:, 1]).clone())
@@ -286,6 +299,7 @@ def gen_e2e(out_dir: str, name: str, spec):
         "margins": torch.stack(margins),                      # [steps, bs] fp32 top-1 minus top-2 logit
         "top1_logits": torch.stack(tops),                     # [steps, bs] fp32 value of the winning logit
         "logits_slices": torch.stack(slices),                 # [steps, bs, 64] bf16
+        "logits_wide": torch.stack(wide),                     # [steps, bs, 2048] bf16: every (vocab // 2048)-th column
         "out_cache_loc_first": locs[0], "out_cache_loc_decode": torch.stack(locs[1:]),
         "req_to_token_rows": torch.cat([r2t.req_to_token[r.req_pool_idx, : len(r.token_ids) - 1] for r in reqs]),
     }

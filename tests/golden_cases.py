@@ -52,10 +52,11 @@ def extend_inputs(case):
                 inp=torch.tensor(inp, dtype=torch.int32))
 
 
-def run_e2e(name, device, layers=None, backend_factory=None, new_tokens=None, use_graph=False, kv_layout="split"):
+def run_e2e(name, device, layers=None, backend_factory=None, new_tokens=None, use_graph=False, kv_layout="split", forced_tokens=None):
     """Greedy generation of an E2E case through the runtime harness.  Returns tokens [bs, T], per-step top-1
-    logit and margin [T, bs], logits slices [T, bs, 64], out_cache_loc (first, decode steps) and the final
-    req_to_token rows — the same quantities the fixture holds."""
+    logit and margin [T, bs], logits slices [T, bs, 64] and [T, bs, 2048], out_cache_loc (first, decode steps) and
+    the final req_to_token rows — the same quantities the fixture holds.  forced_tokens [bs, T]: teacher forcing, the
+    token appended after step t is forced_tokens[:, t] whatever was sampled (the returned tokens are the sampled ones)."""
     from mini_sglang_amd.mem_cache import MHAKVPool, PageAllocator, ReqToTokenPool
     from mini_sglang_amd.runtime.batch_info import BatchInfo, Req, SamplingParams
     from mini_sglang_amd.runtime.model_runner import ModelConfig, ModelRunner, ServerArgs
@@ -75,29 +76,36 @@ def run_e2e(name, device, layers=None, backend_factory=None, new_tokens=None, us
     prompts = gg.e2e_prompts(pseed, plens, cfg.vocab_size)
     reqs = [Req(i, p, SamplingParams(0.0)) for i, p in enumerate(prompts)]
     batch = BatchInfo.init_new(reqs, r2t, pa, kv)
-    margins, tops, slices, locs = [], [], [], []
+    margins, tops, slices, locs, wide, sampled = [], [], [], [], [], []
 
     def record(lg):
+        wide.append(gg.wide_slice(lg).cpu().clone())
         t = lg.float().topk(2, dim=-1).values
         margins.append((t[:, 0] - t[:, 1]).cpu())
         tops.append(t[:, 0].cpu())
         slices.append(lg[:, :64].cpu().clone())
         locs.append(batch.out_cache_loc.cpu().to(torch.int32).clone())
 
+    def take(lg, step):
+        sampled.append(mr.process_result(batch, lg))
+        if forced_tokens is not None:
+            for r, t in zip(reqs, forced_tokens[:, step].tolist()):
+                r.token_ids[-1] = int(t)
+
     batch.prepare_for_extend()
     lg, _ = mr.forward_generate(batch)
     record(lg)
-    mr.process_result(batch, lg)
+    take(lg, 0)
     graph_steps = 0
-    for _ in range(new_tokens - 1):
+    for step in range(1, new_tokens):
         batch.prepare_for_decode()
         lg, in_graph = mr.forward_generate(batch)
         graph_steps += int(in_graph)
         record(lg)
-        mr.process_result(batch, lg)
+        take(lg, step)
     return dict(
-        tokens=torch.tensor([r.token_ids[len(p):] for r, p in zip(reqs, prompts)], dtype=torch.int32),
-        margins=torch.stack(margins), top1_logits=torch.stack(tops), logits_slices=torch.stack(slices),
+        tokens=torch.tensor(sampled, dtype=torch.int32).t().contiguous(),
+        margins=torch.stack(margins), top1_logits=torch.stack(tops), logits_slices=torch.stack(slices), logits_wide=torch.stack(wide),
         out_cache_loc_first=locs[0], out_cache_loc_decode=torch.stack(locs[1:]),
         req_to_token_rows=torch.cat([r2t.req_to_token[r.req_pool_idx, : len(r.token_ids) - 1].cpu() for r in reqs]),
         graph_steps=graph_steps)

@@ -70,7 +70,7 @@ def test_attention_vs_reference_fixture():
         assert err <= 2e-2, f"extend case {ci}: {err}"
 
 
-def _check_e2e(got, fx, need_identical_stream):
+def _check_e2e(got, fx, need_identical_stream, wide_tol=2e-2):
     # integer outputs: slot assignment and page tables never depend on the sampled tokens
     for key in ("out_cache_loc_first", "out_cache_loc_decode", "req_to_token_rows"):
         assert torch.equal(got[key], fx[key]), key
@@ -86,7 +86,11 @@ def _check_e2e(got, fx, need_identical_stream):
         steps += 1  # the logits of the first weak step were still computed from identical inputs
     d_top = (got["top1_logits"][:steps] - fx["top1_logits"][:steps]).abs().max().item()
     d_sl = (got["logits_slices"][:steps].float() - fx["logits_slices"][:steps].float()).abs().max().item()
-    assert d_top <= 2e-2 and d_sl <= 2e-2, (d_top, d_sl)
+    # 2048 columns spread over the whole vocabulary, every step
+    d_wide = (got["logits_wide"][:steps].float() - fx["logits_wide"][:steps].float()).abs().max().item()
+    assert d_top <= 2e-2 and d_sl <= 2e-2 and d_wide <= wide_tol, (d_top, d_sl, d_wide)
+    beyond_one_ulp = ((got["logits_wide"][:steps].float() - fx["logits_wide"][:steps].float()).abs() > 0.0157).float().mean().item()
+    assert beyond_one_ulp <= 0.01, beyond_one_ulp  # 0.0157: one bf16 ulp of the largest logits in these cases (|x| < 4)
 
 
 @pytest.mark.parametrize("name,strict", [("tiny_ps1", False), ("tiny_ps16", True), ("qwen3_0.6b_ps1", True)])
@@ -95,7 +99,37 @@ def test_e2e_greedy_stream_vs_reference_fixture(name, strict):
     cases: HIP attention backend + HIP layers reproduce the reference's token stream, logits within 2e-2."""
     fx = gc.load(f"e2e_{name}.pt")
     got = gc.run_e2e(name, DEV, kv_layout="interleaved")
-    _check_e2e(got, fx, strict)
+    # tiny_ps1 (tied random head, weights of std 0.05) is the noisy case: over all 2048 vocabulary columns the ORACLE
+    # executed on this GPU (same arithmetic as the fixture, hipBLASLt instead of the CPU GEMM) is itself 3.1e-2 away
+    # from the fixture, two bf16 ulps of a logit between 1 and 2; the stated 2e-2 holds for the other cases, among
+    # them the first configuration of the benchmark family
+    _check_e2e(got, fx, strict, wide_tol=2e-2 if strict else 4e-2)
+
+
+def test_e2e_random_head_teacher_forced_logits_vs_reference_fixture():
+    """Qwen3-0.6B shape with a random (not successor) lm_head, 256 steps: the reference's own tokens are fed back
+    after every step, so every step's logits come from the same context as the reference's and carry the 2e-2 bound,
+    2048 columns spread over the vocabulary plus the winning logit, with no help from a wide top-2 margin.  Where the
+    reference's margin is comfortable (4 bf16 ulps at the winning logit's magnitude) the sampled token must be the same as well."""
+    name = "qwen3_0.6b_ps1_random_head"
+    fx = gc.load(f"e2e_{name}.pt")
+    got = gc.run_e2e(name, DEV, kv_layout="interleaved", forced_tokens=fx["tokens"])
+    for key in ("out_cache_loc_first", "out_cache_loc_decode", "req_to_token_rows"):
+        assert torch.equal(got[key], fx[key]), key
+    d_wide = (got["logits_wide"].float() - fx["logits_wide"].float()).abs().max().item()
+    d_top = (got["top1_logits"] - fx["top1_logits"]).abs().max().item()
+    assert d_wide <= 2e-2 and d_top <= 2e-2, (d_wide, d_top)
+    ulp = torch.exp2(torch.floor(torch.log2(fx["top1_logits"].abs())) - 7)   # one bf16 ulp at the winning logit's magnitude
+    clear = (fx["margins"] >= 4 * ulp).t()                                   # [bs, steps]
+    assert bool((got["tokens"] == fx["tokens"])[clear].all())
+    assert float(clear.float().mean()) > 0.4, "the case is meant to have many decidable steps"
+    # and the HIP path is no further from the reference than the reference's own arithmetic is on this device: the
+    # oracle stack on the GPU (same torch operations as the fixture's producer, hipBLASLt GEMMs) sets the noise floor
+    from oracle import modules_oracle as mo
+    floor = gc.run_e2e(name, DEV, layers=mo, backend_factory=mo.OracleAttnBackend, new_tokens=64, forced_tokens=fx["tokens"])
+    mean_hip = (got["logits_wide"][:64].float() - fx["logits_wide"][:64].float()).abs().mean().item()
+    mean_floor = (floor["logits_wide"].float() - fx["logits_wide"][:64].float()).abs().mean().item()
+    assert mean_hip <= 1.25 * mean_floor + 1e-4, (mean_hip, mean_floor)
 
 
 @pytest.mark.parametrize("name", ["tiny_ps16", "qwen3_0.6b_ps1"])

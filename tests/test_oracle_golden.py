@@ -56,7 +56,8 @@ def test_e2e_fixture_matches_oracle_harness(name):
     assignments and the final page table."""
     fx = gc.load(f"e2e_{name}.pt")
     got = gc.run_e2e(name, "cpu", layers=mo, backend_factory=mo.OracleAttnBackend)
-    for key in ("tokens", "margins", "top1_logits", "logits_slices", "out_cache_loc_first", "out_cache_loc_decode", "req_to_token_rows"):
+    for key in ("tokens", "margins", "top1_logits", "logits_slices", "logits_wide", "out_cache_loc_first", "out_cache_loc_decode",
+                "req_to_token_rows"):
         assert torch.equal(got[key], fx[key]), key
 
 

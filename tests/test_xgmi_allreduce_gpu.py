@@ -11,6 +11,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -100,3 +101,44 @@ def test_bench_trial_validates_and_times():
         assert p.returncode == 0 and lines, out[-2000:]
         info = json.loads(lines[-1][6:])
         assert info["validated"] and set(info["sizes"]) == {"1x4096", "16x4096", "64x4096", "256x4096"}, info
+
+
+def test_bench_tensor_parallel_control_flow_end_to_end(tmp_path):
+    """bench.py's N > 1 path from start to finish, two ranks on this box's GPU over gloo: headline measurement with
+    heads divided over the ranks, the secondary shapes, the all-reduce trial in child processes, and both whole-model
+    decode legs (eager, hidden-state all-reduces on the direct-read kernels) — so that the first run on a real
+    multi-GPU node is not also the first execution of that code.  Only the plumbing is checked, not the numbers."""
+    import json
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               OMP_NUM_THREADS="2")
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    cmd = [sys.executable, "-u", bench, "--gpus", "2", "--dist-backend", "gloo", "--steps", "3", "--warmup", "1", "--bs", "16", "--ctx", "1024",
+           "--layers", "2", "--e2e-steps", "2", "--e2e-ctx", "512", "--mixed-bs", "16", "--secondary-deadline", "400"]
+    env["MSGL_BENCH_TRACE"] = "1"  # a progress line per leg on stderr: a rank that stops says where
+    logs = [open(os.path.join(str(tmp_path), f"rank{r}.log"), "w+") for r in range(2)]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=logs[r], stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    deadline = time.monotonic() + 150
+    while any(p.poll() is None for p in procs) and time.monotonic() < deadline:
+        time.sleep(1)
+    late = [p for p in procs if p.poll() is None]
+    for p in late:
+        p.kill()
+        p.wait()
+    outs = []
+    for f in logs:
+        f.seek(0)
+        outs.append(f.read())
+        f.close()
+    assert not late and all(p.returncode == 0 for p in procs), "\n".join(f"--- rank {r}\n{o[-3000:]}" for r, o in enumerate(outs))
+    lines = [ln for ln in outs[0].splitlines() if ln.startswith("{")]
+    assert lines, outs[0][-3000:]
+    res = json.loads(lines[-1])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["config"]["hkv_per_gpu"] == 4 and res["scaling"] == "strong"
+    assert "secondary_timeout_s" not in res
+    assert res["tp_allreduce"]["validated"], res["tp_allreduce"]
+    for leg in ("decode_e2e", "decode_e2e_mixed"):
+        assert "error" not in res[leg] and "skipped" not in res[leg] and res[leg]["tok_per_s"] > 0, (leg, res[leg])
+        assert res[leg]["tp"] == 2 and res[leg]["hip_graph"] is False
+    assert "error" not in res["other_configs"] and "error" not in res["extend"], (res["other_configs"], res["extend"])
