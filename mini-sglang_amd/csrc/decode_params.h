@@ -55,4 +55,39 @@ __device__ __forceinline__ SplitInfo split_info(const DecodeParams& p, int b, in
     return r;
 }
 
+// End of a (request, split) work group of either decode kernel: every wave has left its state for its kv head in LDS
+// (lds_o [wave][G][128] unnormalised outputs, lds_ml [wave][G][2] running max in log2 units and running sum) and the
+// group has passed a barrier.  The calling wave, the first of the WPH waves of kv head h, merges them and writes either
+// the final bf16 output (the request has this one split and no partials from another kernel) or the split's partial.
+template <int G, int WPH>
+__device__ __forceinline__ void merge_waves_and_store(const DecodeParams& p, const float* lds_o, const float* lds_ml, int h, int lane, int b,
+                                                      int split, bool final_out) {
+#pragma unroll
+    for (int idx = lane * 2; idx < G * kD; idx += 128) {
+        const int g = idx / kD, d = idx - g * kD;
+        float M = kNegBig;
+#pragma unroll
+        for (int w = 0; w < WPH; ++w) M = fmaxf(M, lds_ml[((h * WPH + w) * G + g) * 2]);
+        float L = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPH; ++w) {
+            const int ww = h * WPH + w;
+            const float f = fast_exp2(lds_ml[(ww * G + g) * 2] - M);
+            L += f * lds_ml[(ww * G + g) * 2 + 1];
+            const float2 o = *reinterpret_cast<const float2*>(lds_o + (ww * G + g) * kD + d);
+            o0 += f * o.x;
+            o1 += f * o.y;
+        }
+        const int hq = h * G + g;
+        if (final_out) {
+            const float inv = 1.0f / L;
+            *reinterpret_cast<uint32_t*>(p.out + (int64_t)b * p.out_stride + hq * kD + d) = pack_bf16(o0 * inv, o1 * inv);
+        } else {
+            const int64_t row = ((int64_t)b * p.max_splits + split) * p.Hq + hq;
+            *reinterpret_cast<float2*>(p.ws_o + row * kD + d) = make_float2(o0, o1);
+            if (d == 0) *reinterpret_cast<float2*>(p.ws_ml + row * 2) = make_float2(M, L);
+        }
+    }
+}
+
 }  // namespace msgl

@@ -26,6 +26,8 @@
 #include "decode_params.h"
 #include "plan_sort.h"
 
+#include <stdlib.h>
+
 #include <mutex>
 #include <type_traits>
 
@@ -362,34 +364,7 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
     __syncthreads();
     if (sub != 0) return;
 
-    // the first wave of every kv head merges the WPH partial states and writes the result
-    const bool final_out = (nsplit == 1 && si.extra == 0);
-#pragma unroll
-    for (int idx = lane * 2; idx < G * kD; idx += 128) {
-        const int g = idx / kD, d = idx - g * kD;
-        float M = kNegBig;
-#pragma unroll
-        for (int w = 0; w < WPH; ++w) M = fmaxf(M, lds_ml[((h * WPH + w) * G + g) * 2]);
-        float L = 0.f, o0 = 0.f, o1 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WPH; ++w) {
-            const int ww = h * WPH + w;
-            const float f = fast_exp2(lds_ml[(ww * G + g) * 2] - M);
-            L += f * lds_ml[(ww * G + g) * 2 + 1];
-            const float2 o = *reinterpret_cast<const float2*>(lds_o + (ww * G + g) * kD + d);
-            o0 += f * o.x;
-            o1 += f * o.y;
-        }
-        const int hq = h * G + g;
-        if (final_out) {
-            const float inv = 1.0f / L;
-            *reinterpret_cast<uint32_t*>(p.out + (int64_t)b * p.out_stride + hq * kD + d) = pack_bf16(o0 * inv, o1 * inv);
-        } else {
-            const int64_t row = ((int64_t)b * p.max_splits + split) * p.Hq + hq;
-            *reinterpret_cast<float2*>(p.ws_o + row * kD + d) = make_float2(o0, o1);
-            if (d == 0) *reinterpret_cast<float2*>(p.ws_ml + row * 2) = make_float2(M, L);
-        }
-    }
+    merge_waves_and_store<G, WPH>(p, lds_o, lds_ml, h, lane, b, split, nsplit == 1 && si.extra == 0);
 }
 
 // Launch order for a ragged decode batch: item = split * bs + request, cost = its number of 16-token tiles.
@@ -538,15 +513,32 @@ __global__ __launch_bounds__(256) void paged_decode_merge_small_kernel(DecodePar
     *reinterpret_cast<uint32_t*>(p.out + (int64_t)b * p.out_stride + hq * kD + d) = pack_bf16(o0 * inv, o1 * inv);
 }
 
+int launch_decode_mfma(const DecodeParams& p, int Hkv, hipStream_t stream);  // paged_decode_mfma.hip
+
+// 8 query heads per kv head on 16-slot runs take the matrix-core kernel (MSGL_DECODE_G8=gather: the vector one)
+static bool use_mfma_decode(int G, int page_size) {
+    if (G != 8 || page_size % kTile != 0) return false;
+    static const bool gather = [] {
+        const char* e = getenv("MSGL_DECODE_G8");
+        return e && e[0] == 'g';
+    }();
+    return !gather;
+}
+
 template <int G, int HPB>
 static int launch_decode(const DecodeParams& p, int page_size, hipStream_t stream) {
     const dim3 grid(p.bs * p.max_splits), block(kWaves * 64);
     const size_t lds = (size_t)kWaves * G * (kD + 2) * sizeof(float);
-    if (page_size % kTile == 0)
-        hipLaunchKernelGGL((paged_decode_kernel<G, HPB, true>), grid, block, lds, stream, p);
-    else
-        hipLaunchKernelGGL((paged_decode_kernel<G, HPB, false>), grid, block, lds, stream, p);
-    int rc = check_launch("paged_decode_kernel");
+    int rc;
+    if (use_mfma_decode(G, page_size)) {
+        rc = launch_decode_mfma(p, HPB, stream);
+    } else {
+        if (page_size % kTile == 0)
+            hipLaunchKernelGGL((paged_decode_kernel<G, HPB, true>), grid, block, lds, stream, p);
+        else
+            hipLaunchKernelGGL((paged_decode_kernel<G, HPB, false>), grid, block, lds, stream, p);
+        rc = check_launch("paged_decode_kernel");
+    }
     if (rc) return rc;
     if (p.max_splits > 1) {
         if (p.max_splits <= 16)  // few splits: a wave per row, four rows per group

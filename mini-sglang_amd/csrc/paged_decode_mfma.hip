@@ -1,0 +1,315 @@
+// Paged decode attention for GQA groups of 8 query heads per kv head (Qwen3-32B) on the matrix cores.
+//
+// The gather kernel of paged_decode.hip does its arithmetic on the vector pipe, and with 8 query heads per
+// K/V row that arithmetic (384 multiply-adds and dot products out of ~520 vector instructions per 16 tokens and
+// wave) is what the kernel waits for, not HBM.  Here the same work items (one work group per (request, split), all
+// local kv heads, a wave per kv head or several waves per head taking every n-th tile) feed 16-token tiles to
+// v_mfma_f32_16x16x32_bf16 (S^T = K.Q^T, the 8 query heads padded to 16 columns) and v_mfma_f32_16x16x16_bf16
+// (O^T += V^T.P^T); the matrix pipe is then busy a few percent of the time and the kernel is paced by its loads.
+//
+//   * K and V rows go from HBM straight into LDS (global_load_lds_dwordx4: no staging registers, no ds_write),
+//     into a ring of two 8 KiB tile slots PER WAVE: tiles are private to a wave, so the loop has no barrier, only
+//     counted s_waitcnt vmcnt.  One instruction moves 4 rows of 256 B; K(n+2) is issued as soon as the K fragments
+//     of tile n are in registers, V(n+2) likewise, so each wave keeps about two tiles (16 KiB) in flight.
+//   * The LDS destination of such a load is lane-linear, the source address is per lane: the XOR swizzles that make
+//     the fragment reads conflict free are applied to the SOURCE (lane p of a row fetches chunk p ^ f(row)).
+//       K rows are read as MFMA A operands with ds_read_b128 (row = token, 16-byte chunk = 8 dims): f(row) = row;
+//       V rows are read transposed with ds_read_b64_tr_b16 (lane <- one dim of 4 tokens):           f(row) = 2 (row & 7).
+//   * S^T comes out with the query head on the lane (lane & 15) and 4 tokens in registers, so a head's row maximum
+//     is 3 in-lane max + two lane swaps, the exponentiated scores packed to bf16 ARE the B operand of the second
+//     product, and the O^T accumulator (8 x 4 registers) has the head on the lane as well: rescaling is in-lane.
+//   * Requires page_size % 16 == 0 (a tile's 16 token rows are consecutive slots, one scalar table read per tile).
+// Split-K, partials, launch plans, start offsets and the merge kernels are those of paged_decode.hip.
+#include <type_traits>
+
+#include "msgl_common.h"
+#include "decode_params.h"
+
+namespace msgl {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mbf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short mshort4_t;
+typedef __attribute__((ext_vector_type(4))) float mf32x4_t;
+
+constexpr int kMG = 8;                  // query heads per kv head
+constexpr int kMKSlots = 2;             // K tiles (16 rows of 256 B = 4 KiB) a wave holds: one being read, the others on their way
+constexpr int kMVSlots = 2;             // V tiles
+constexpr int kMHalf = 4096;            // bytes of a K or V tile
+constexpr int kMWaveBytes = (kMKSlots + kMVSlots) * kMHalf;   // (three K slots, 20 KiB a wave, measured 3-5 % slower than two)
+constexpr int kMLdsBytes = kWaves * kMWaveBytes;
+
+// Four LDS-DMA loads of 4 rows x 256 B each into 4 KiB at LDS byte address `dst`; lane offsets off[i] (bytes from
+// `base`) select the row and the swizzled chunk.  The statement first waits for the wave's outstanding LDS reads (the
+// fragments of the tile that occupied these bytes).  `base` was just written by scalar arithmetic: s_nop 4 before the
+// first load reads it; M0 is written and read inside the statement.
+template <bool NT>
+__device__ __forceinline__ void dma_rows16(const void* base, uint32_t dst, const uint32_t (&off)[4]) {
+    unsigned keep;
+    if (NT)
+        asm volatile(
+            "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_nop 4\n\t"
+            "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 nt\n\t"
+            "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1 nt\n\t"
+            "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1 nt\n\t"
+            "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1 nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "s"(base), "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(dst), "s"(dst + 1024), "s"(dst + 2048), "s"(dst + 3072)
+            : "memory");
+    else
+        asm volatile(
+            "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_nop 4\n\t"
+            "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+            "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+            "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+            "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "s"(base), "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(dst), "s"(dst + 1024), "s"(dst + 2048), "s"(dst + 3072)
+            : "memory");
+}
+
+// wait until at most `groups` of the wave's four-load groups are outstanding (loads complete in issue order)
+__device__ __forceinline__ void wait_dma_groups(int groups) {
+    switch (groups) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    }
+}
+
+// max over the four lanes that hold the same query head (lane, lane ^ 16, lane ^ 32, lane ^ 48)
+__device__ __forceinline__ float max_over_lane_groups(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    x = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
+    u = __builtin_bit_cast(unsigned, x);
+    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1]));
+}
+
+template <int HPB>
+__global__ __launch_bounds__(kWaves * 64) void paged_decode_mfma_kernel(DecodeParams p) {
+    constexpr int G = kMG;
+    constexpr int WPH = kWaves / HPB;  // waves sharing one kv head
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    int item = blockIdx.x;
+    if (p.plan) {
+        item = p.plan[blockIdx.x];
+        if (item < 0) return;
+    }
+    const int split = item / p.bs;
+    const int b = item - split * p.bs;
+    const int chunk = split_chunk(p);
+    const SplitInfo si = split_info(p, b, chunk);
+    const int S = si.S, nsplit = si.nsplit;
+    if (split >= nsplit) return;
+    const int t0 = si.start + split * chunk;  // a multiple of 16: tiles never straddle a 16-slot run
+    const int t1 = (split == p.max_splits - 1) ? S : min(S, t0 + chunk);
+    const int ntiles = (t1 - t0 + kTile - 1) / kTile;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g4 = lane >> 4;   // S^T / O^T: which 4 rows of a 16-row block; LDS-DMA: which of an instruction's 4 rows
+    const int qn = lane & 15;   // S^T / O^T: query head (8 .. 15 are padding); LDS-DMA: 16-byte position inside the row
+    const int h = wave / WPH;
+    const int sub = wave - h * WPH;
+    const int my_tiles = (ntiles > sub) ? (ntiles - sub + WPH - 1) / WPH : 0;  // own tiles: sub, sub + WPH, ...
+
+    const int32_t* r2t_row = p.r2t + (int64_t)p.req_idx[b] * p.r2t_stride;
+    // LDS byte address of this wave's ring (what M0 takes)
+    const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)wave * kMWaveBytes;
+    const char* ring_ptr = smem + wave * kMWaveBytes;  // [kMKSlots K tiles][kMVSlots V tiles]
+
+    // Q^T fragments (B operand of S^T = K.Q^T): lane (head qn, group g4) holds dims 32 ks + 8 g4 .. + 8
+    uint4 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = qn < G ? *reinterpret_cast<const uint4*>(p.q + (int64_t)b * p.q_stride + (h * G + qn) * kD + ks * 32 + g4 * 8) : make_uint4(0, 0, 0, 0);
+
+    // the query is in registers before the first LDS-DMA load is issued: a use the compiler sees, so that it waits for
+    // these loads here and not, with a full vmcnt(0), at their first use inside the tile loop
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[ks].x), "v"(qf[ks].y), "v"(qf[ks].z), "v"(qf[ks].w));
+
+    // source offsets of the LDS-DMA loads: instruction i brings rows 4 i + g4 of the tile; position qn of row r gets chunk
+    // qn ^ r (K) or qn ^ 2 (r & 7) (V).  Bytes from the tile's first row of this kv head.
+    uint32_t koff[4], voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * i + g4;
+        koff[i] = (uint32_t)(r * p.cache_stride * 2 + ((qn ^ r) << 4));
+        voff[i] = (uint32_t)(r * p.cache_stride * 2 + ((qn ^ (2 * (r & 7))) << 4));
+    }
+    // LDS offsets of the fragment reads inside a tile slot.
+    // K, k-step ks: row qn, chunk (4 ks + g4) ^ qn.
+    uint32_t kread[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kread[ks] = (uint32_t)(qn * 256 + (((4 * ks + g4) ^ qn) << 4));
+    // V, block mb of 16 dims: lane i = qn of a 16-lane group addresses row 4 g4 + (i >> 2), 8-byte segment i & 3 of the
+    // block's 32 bytes, and receives dim 16 mb + i of the group's 4 rows (tokens 4 g4 .. 4 g4 + 3).
+    const int vrow = 4 * g4 + (qn >> 2), vseg = qn & 3;
+    uint32_t vread[8];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+        vread[mb] = (uint32_t)(vrow * 256 + (((2 * mb + (vseg >> 1)) ^ (2 * (vrow & 7))) << 4) + (vseg & 1) * 8);
+
+    mf32x4_t o[8];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) o[mb] = mf32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m = kNegBig, l = 0.f;  // running max (log2 units) of this lane's head; this lane's share of the running sum
+
+    const int reuse_len = !p.kv_stream ? 0x7fffffff : (p.reuse_lens ? p.reuse_lens[b] : 0);
+    // Page-table entry of own tile n (the slot of its first token; the other 15 follow it), by a scalar load that the
+    // compiler does not count: a vector load here would make it wait for "all" vector memory operations, the LDS-DMA
+    // loads in flight included.  Tiles past the wave's last one read the last one's entry.  table_wait makes the
+    // value usable (the load and its wait are separate statements so that other work can sit between them).
+    auto table_load = [&](int n) -> int {
+        const int tok = t0 + (sub + min(n, my_tiles - 1) * WPH) * kTile;
+        int idx;
+        asm volatile("s_load_dword %0, %1, %2" : "=s"(idx) : "s"(r2t_row), "s"(tok * 4) : "memory");
+        return idx;
+    };
+    auto table_wait = [&](int& idx) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(idx)::"memory"); };
+    auto issue_k = [&](int n, int idx) {
+        const uint16_t* kb = p.kc + ((int64_t)idx * p.cache_stride + h * kD);
+        const uint32_t dst = ring + (uint32_t)(n % kMKSlots) * kMHalf;
+        if (t0 + (sub + n * WPH) * kTile >= reuse_len) dma_rows16<true>(kb, dst, koff);
+        else dma_rows16<false>(kb, dst, koff);
+    };
+    auto issue_v = [&](int n, int idx) {
+        const uint16_t* vb = p.vc + ((int64_t)idx * p.cache_stride + h * kD);
+        const uint32_t dst = ring + (uint32_t)(kMKSlots + (n & 1)) * kMHalf;
+        if (t0 + (sub + n * WPH) * kTile >= reuse_len) dma_rows16<true>(vb, dst, voff);
+        else dma_rows16<false>(vb, dst, voff);
+    };
+    // Issue order of the wave's load groups (4 loads each): K0 V0 K1 V1 (K2 with three K slots) up front, then tile i issues
+    // K(i + KA), KA = kMKSlots, once its K fragments are in registers and V(i+2) once its V fragments are.  Loads complete in that order, so "K(n) has
+    // landed" is "at most (groups issued so far - 1 - position of K(n)) groups outstanding".
+    const int T = my_tiles;
+    constexpr int KA = kMKSlots;
+    static_assert(KA == 2 || KA == 3, "K tiles in flight");
+    const int up_front = (T >= 1 ? 2 : 0) + (T >= 2 ? 2 : 0) + (KA == 3 && T >= 3 ? 1 : 0);
+    auto issued_before_tile = [&](int i) { return up_front + min(i, max(0, T - KA)) + min(i, max(0, T - 2)); };
+    auto pos_k = [&](int j) { return j < KA ? 2 * j : issued_before_tile(j - KA); };
+    auto pos_v = [&](int j) { return j < 2 ? 2 * j + 1 : issued_before_tile(j - 2) + ((j - 2 + KA < T) ? 1 : 0); };
+
+    if (T > 0) {
+        int ia = table_load(0), ib = table_load(1), ic = table_load(2);
+        table_wait(ia), table_wait(ib), table_wait(ic);
+        issue_k(0, ia);
+        issue_v(0, ia);
+        if (T > 1) issue_k(1, ib), issue_v(1, ib);
+        if (KA == 3 && T > 2) issue_k(2, ic);
+        // table entries at hand while tile n is worked on: of tile n + 2 (for its V) and of tile n + KA (for its K)
+        int idx_v = ic, idx_k = ic;
+        if (KA == 3) {
+            idx_k = table_load(3);
+            table_wait(idx_k);
+        }
+        for (int n = 0; n < T; ++n) {
+            const char* kslot = ring_ptr + (n % kMKSlots) * kMHalf;
+            const char* vslot = ring_ptr + (kMKSlots + (n & 1)) * kMHalf;
+            const int before = issued_before_tile(n);
+            const bool more_k = n + KA < T, more_v = n + 2 < T;
+            wait_dma_groups(before - 1 - pos_k(n));
+            uint4 kf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(kslot + kread[ks]);
+            if (more_k) issue_k(n + KA, idx_k);  // (waits for the four reads above first)
+            int idx_after = table_load(n + KA + 1);  // used by the next iteration; waited for at the end of this one
+            mf32x4_t s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mbf16x8_t, kf[ks]), __builtin_bit_cast(mbf16x8_t, qf[ks]), s, 0, 0, 0);
+            // scores of tokens tok0 + r for head qn
+            const int tok0 = t0 + (sub + n * WPH) * kTile + 4 * g4;
+            float sc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[r] = (tok0 + r < t1) ? s[r] * p.scale_log2e : -INFINITY;
+            const float mt = max_over_lane_groups(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
+            const float mn = fmaxf(m, mt);
+            const float alpha = fast_exp2(m - mn);
+            m = mn;
+            float pr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pr[r] = fast_exp2(sc[r] - mn);
+            l = l * alpha + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
+            if (!__all(alpha == 1.0f)) {  // the running max settles after a few tiles
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[mb][r] *= alpha;
+            }
+            // P^T as the B operand of O^T += V^T.P^T: k = tokens 4 g4 + j, n = head qn
+            const uint2 pp = make_uint2(pack_bf16(pr[0], pr[1]), pack_bf16(pr[2], pr[3]));
+            const mshort4_t pfrag = __builtin_bit_cast(mshort4_t, pp);
+            wait_dma_groups(before + (more_k ? 1 : 0) - 1 - pos_v(n));
+            mshort4_t vf[8];
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb)
+                vf[mb] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) mshort4_t*)(vslot + vread[mb]));
+            if (more_v) issue_v(n + 2, idx_v);
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) o[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[mb], pfrag, o[mb], 0, 0, 0);
+            table_wait(idx_after);
+            idx_v = KA == 3 ? idx_k : idx_after;
+            idx_k = idx_after;
+        }
+    }
+
+    // this lane's head: total of the four lane groups' sums
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    // every wave is done with its ring (no load outstanding, all fragments in registers): the memory becomes the
+    // exchange area of the merge
+    wait_dma_groups(0);
+    __syncthreads();
+    float* lds_o = reinterpret_cast<float*>(smem);       // [kWaves][G][128]
+    float* lds_ml = lds_o + kWaves * G * kD;              // [kWaves][G][2]
+    if (qn < G) {
+        float* dst = lds_o + (wave * G + qn) * kD + 4 * g4;
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) *reinterpret_cast<float4*>(dst + 16 * mb) = make_float4(o[mb][0], o[mb][1], o[mb][2], o[mb][3]);
+        if (g4 == 0) {
+            lds_ml[(wave * G + qn) * 2] = m;
+            lds_ml[(wave * G + qn) * 2 + 1] = l;
+        }
+    }
+    __syncthreads();
+    if (sub != 0) return;
+    merge_waves_and_store<G, WPH>(p, lds_o, lds_ml, h, lane, b, split, nsplit == 1 && si.extra == 0);
+}
+
+template <int HPB>
+static int launch_mfma(const DecodeParams& p, hipStream_t stream) {
+    static bool configured = false;  // the rings need more than the 64 KiB a kernel gets by default
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(paged_decode_mfma_kernel<HPB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kMLdsBytes) != hipSuccess) {
+            set_error("msgl_paged_decode: cannot reserve %d bytes of LDS", kMLdsBytes);
+            return MSGL_E_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(paged_decode_mfma_kernel<HPB>, dim3(p.bs * p.max_splits), dim3(kWaves * 64), kMLdsBytes, stream, p);
+    return check_launch("paged_decode_mfma_kernel");
+}
+
+// The main launch of a decode call with 8 query heads per kv head and 16-slot runs; the caller launches the merge.
+int launch_decode_mfma(const DecodeParams& p, int Hkv, hipStream_t stream) {
+    switch (Hkv) {
+        case 1: return launch_mfma<1>(p, stream);
+        case 2: return launch_mfma<2>(p, stream);
+        case 4: return launch_mfma<4>(p, stream);
+        case 8: return launch_mfma<8>(p, stream);
+    }
+    set_error("msgl_paged_decode: Hkv=%d unsupported (1, 2, 4 or 8 local kv heads)", Hkv);
+    return MSGL_E_INVALID;
+}
+
+}  // namespace msgl
