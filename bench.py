@@ -459,8 +459,14 @@ def extend_attention(args, world, rank):
         cu = torch.tensor([0, Sq], dtype=torch.int32, device=dev)
         pre = torch.tensor([prefix], dtype=torch.int32, device=dev)
 
+        # as HipAttnBackend.forward_extend does: a launch of fewer work items (128-row query tiles x head pairs) than
+        # compute units gets a workspace, and the library cuts the items' key ranges into runs
+        ws = None
+        if -(-Sq // 128) * max(1, Hq // 2) < torch.cuda.get_device_properties(dev).multi_processor_count and S >= 2048:
+            ws = torch.empty(ops.extend_workspace_bytes(Sq, Hq, D), dtype=torch.uint8, device=dev)
+
         def f():
-            ops.paged_extend(q, kv[:, 0], kv[:, 1], r2t, idx, cu, pre, Sq, D ** -0.5, ps, out=out, max_seqlen_k=S)
+            ops.paged_extend(q, kv[:, 0], kv[:, 1], r2t, idx, cu, pre, Sq, D ** -0.5, ps, out=out, max_seqlen_k=S, workspace=ws)
 
         for _ in range(3):
             f()
@@ -474,7 +480,7 @@ def extend_attention(args, world, rank):
         ms = e0.elapsed_time(e1) / steps
         tf = 4 * Hq * D * Sq * (prefix + (Sq + 1) / 2) / (ms * 1e-3) / 1e12
         what = f"one {Sq}-token prompt" + (f" on a {prefix}-token cached prefix" if prefix else "")
-        return {"workload": f"{what}, {Hq} q / {Hkv} kv heads per GPU, page_size {ps}", "ms_per_launch": round(ms, 4),
+        return {"workload": f"{what}, {Hq} q / {Hkv} kv heads per GPU, page_size {ps}", "ms_per_launch": round(ms, 4), "key_split_workspace": ws is not None,
                 "TFLOPs_per_gpu": round(tf, 1),
                 "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4)}}
 

@@ -205,6 +205,14 @@ int msgl_shared_prefix_decode(const void* q, int64_t q_stride,
  * The new tokens' K/V must already be in the pool (msgl_store_kv first), as in
  * torch_attn_backend.py:195-196.
  * ------------------------------------------------------------------------- */
+/* workspace (optional, NULL / 0 = none): msgl_paged_extend_workspace_bytes(total_tokens, Hq, D) bytes
+ * of 16-byte aligned device memory, total_tokens = cu_seqlens_q[bs] (the host knows it: it
+ * sized q).  With it, a launch of few work items over long key ranges (a short prompt on a
+ * long cached prefix, few heads per GPU) cuts every item's keys into up to 8 runs, one work
+ * group each, and a second small kernel joins the partial results; without it such a launch
+ * leaves compute units idle or half occupied.  Results agree to fp32 rounding of the sums. */
+size_t msgl_paged_extend_workspace_bytes(int64_t total_tokens, int Hq, int D);
+
 int msgl_paged_extend(const void* q, int64_t q_stride,
                       const void* k_cache, const void* v_cache, int64_t cache_stride,
                       const int32_t* req_to_token, int64_t r2t_stride,
@@ -213,7 +221,8 @@ int msgl_paged_extend(const void* q, int64_t q_stride,
                       void* out, int64_t out_stride,
                       int bs, int max_seqlen_q, int max_seqlen_k, const int32_t* plan,
                       int Hq, int Hkv, int D, int page_size,
-                      float scale, void* stream);
+                      float scale, void* workspace, size_t workspace_bytes, int64_t total_tokens,
+                      void* stream);
 
 /* ---------------------------------------------------------------------------
  * Launch order for msgl_paged_extend on a ragged batch, computed on the device

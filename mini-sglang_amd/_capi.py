@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSGL_HIP_LIB", os.path.join(_HERE, "libmsgl_hip.so"))
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # name -> (restype, argtypes); mirrors include/msgl_hip.h and include/msgl_comm.h one to one
 SIGNATURES = {
@@ -45,8 +45,9 @@ SIGNATURES = {
     "msgl_paged_extend": (
         c_int,
         [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-         c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p],
+         c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_int64, c_void_p],
     ),
+    "msgl_paged_extend_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "msgl_extend_plan_items": (c_int64, [c_int, c_int]),
     "msgl_extend_plan": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "msgl_rmsnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),

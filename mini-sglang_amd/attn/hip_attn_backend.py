@@ -77,6 +77,7 @@ class HipAttnBackend(AttentionBackend):
         # use a buffer of their own that grows on demand.
         self._graph_workspace: Optional[torch.Tensor] = None
         self._eager_workspace: Optional[torch.Tensor] = None
+        self._extend_workspace: Optional[torch.Tensor] = None
         # K/V rows are read once per step: stream them past the caches (non-temporal), keeping only the
         # prefix positions that several requests share cacheable
         self.kv_stream = True
@@ -112,6 +113,19 @@ class HipAttnBackend(AttentionBackend):
                                    "metadata from init_forward_metadata_capture_cuda_graph")
             self._eager_workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._eager_workspace
+
+    def _extend_workspace_for(self, md: HipAttnMetadata, batch, T: int, layer) -> Optional[torch.Tensor]:
+        """Room for key-split partials when the extend launch would not cover the chip (few 128-row query tiles x head
+        pairs with long key ranges: a short prompt on a long cached prefix, few heads per rank); None otherwise.  Extend
+        is never captured, so the buffer may grow between forwards."""
+        pairs = layer.num_heads // (2 if (layer.num_heads // layer.num_kv_heads) % 2 == 0 else 1)
+        items = batch.seq_lens.numel() * -(-md.max_seqlen_q // 128) * pairs
+        if md.max_seqlen_k < 2048 or items >= self._cus:
+            return None
+        need = ops.extend_workspace_bytes(T, layer.num_heads, layer.head_dim)
+        if self._extend_workspace is None or self._extend_workspace.numel() < need:
+            self._extend_workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._extend_workspace
 
     def _decode_split(self, seq_lens_cpu: torch.Tensor, bs: int, max_splits: int):
         """(tokens per split, ragged).  A batch whose longest request is well above the average is launched in
@@ -190,7 +204,7 @@ class HipAttnBackend(AttentionBackend):
         o = ops.paged_extend(
             _as_heads(q, layer.num_heads, layer.head_dim), k_cache, v_cache, self.req_to_token_pool.req_to_token,
             batch.req_pool_indices, md.cu_seqlens_q, batch.prefix_seq_lens, md.max_seqlen_q, layer.scale, self.page_size,
-            max_seqlen_k=md.max_seqlen_k, plan=md.extend_plan)
+            max_seqlen_k=md.max_seqlen_k, plan=md.extend_plan, workspace=self._extend_workspace_for(md, batch, T, layer))
         return o.view(T, layer.num_heads * layer.head_dim)
 
     def forward_decode(self, q, k, v, layer, batch, save_kv_cache: bool = True):

@@ -36,5 +36,5 @@ int device_cus() {
 
 }  // namespace msgl
 
-extern "C" int msgl_abi_version(void) { return 12; }
+extern "C" int msgl_abi_version(void) { return 13; }
 extern "C" const char* msgl_last_error(void) { return msgl::g_err; }

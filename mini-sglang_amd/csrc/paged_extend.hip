@@ -61,6 +61,12 @@ struct ExtendParams {
     int group;  // query heads per kv head
     float scale_log2e;
     const int32_t* plan;  // optional: (request, query tile) items in launch order, see extend_plan_kernel
+    // Key split: ksplit > 1 cuts every work item's key tiles into ksplit equal runs, one work group each, so that a
+    // launch of few items with long key ranges still covers the chip; the groups leave partial results (unnormalised
+    // O, running max, sum: [token][head][split]) in ws_o / ws_ml and extend_merge_kernel joins them.
+    int ksplit;
+    float* ws_o;
+    float* ws_ml;
 };
 
 // Shared-prefix mode (GROUPED): the "query rows" of a work group are the decode queries of the requests that share
@@ -213,10 +219,12 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
     const int idx = blockIdx.x;
     hk = idx % p.hkv;
     const int hs = (idx / p.hkv) % hsets;
-    int b = (idx / (p.hkv * hsets)) % p.bs;
-    int qt = p.tiles_per_req - 1 - idx / (p.hkv * hsets * p.bs);
+    g_split = (idx / (p.hkv * hsets)) % p.ksplit;  // which run of key tiles (0 when the keys are not split)
+    const int per_item = p.hkv * hsets * p.ksplit;
+    int b = (idx / per_item) % p.bs;
+    int qt = p.tiles_per_req - 1 - idx / (per_item * p.bs);
     if (p.plan) {  // ragged batches: items sorted by their number of key tiles, longest first
-        const int item = p.plan[idx / (p.hkv * hsets)];
+        const int item = p.plan[idx / per_item];
         if (item < 0) return;
         b = item / p.tiles_per_req;
         qt = item - b * p.tiles_per_req;
@@ -231,13 +239,26 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
     const int row0 = qt * kBM + (wave & 3) * 32;  // first query row of this wave
     const int qrow = row0 + n;
     qvalid = qrow < Sq;
-    qpos = prefix + qrow;  // last key position this lane's query may see
-    // tiles [0, full_nkt) are visible to every row of the wave, [full_nkt, my_nkt) partly, the rest not at all
-    full_nkt = (prefix + row0 + 1) / kBN;
-    my_nkt = (row0 < Sq) ? min(nkt, (prefix + row0 + 31) / kBN + 1) : 0;
-    r2t_row = p.r2t + (int64_t)p.req_idx[b] * p.r2t_stride;
-    qp = p.q + (int64_t)(q0 + (qvalid ? qrow : 0)) * p.q_stride + hq * kHD + h * 8;
     out_row = q0 + qrow;
+    // this group's keys are positions [key0, key0 + kv_len); everything below counts positions from key0
+    int key0 = 0;
+    if (p.ksplit > 1) {
+        const int per_split = (nkt + p.ksplit - 1) / p.ksplit;
+        key0 = g_split * per_split * kBN;
+        if (key0 >= kv_len) {  // nothing left for this run: an empty partial (the merge skips it by its running max)
+            if (qvalid && h == 0) *reinterpret_cast<float2*>(p.ws_ml + (((int64_t)out_row * (p.hkv * p.group) + hq) * p.ksplit + g_split) * 2) =
+                    make_float2(kNegBigE, 0.f);
+            return;
+        }
+        kv_len = min(kv_len - key0, per_split * kBN);
+        nkt = (kv_len + kBN - 1) / kBN;
+    }
+    qpos = prefix + qrow - key0;  // last key position this lane's query may see
+    // tiles [0, full_nkt) are visible to every row of the wave, [full_nkt, my_nkt) partly, the rest not at all
+    full_nkt = min(nkt, max(0, prefix + row0 + 1 - key0) / kBN);
+    my_nkt = (row0 < Sq && prefix + row0 + 31 >= key0) ? min(nkt, (prefix + row0 + 31 - key0) / kBN + 1) : 0;
+    r2t_row = p.r2t + (int64_t)p.req_idx[b] * p.r2t_stride + key0;
+    qp = p.q + (int64_t)(q0 + (qvalid ? qrow : 0)) * p.q_stride + hq * kHD + h * 8;
     }
 
     // Q^T fragments: B operand, lane (n, h) holds Q[n][16*ks + 8*h .. +8)
@@ -539,6 +560,18 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
         if (h == 0) *reinterpret_cast<float2*>(dp.ws_ml + row * 2) = make_float2(m, l);
         return;
     }
+    if (p.ksplit > 1) {  // partial of (token, head, key run)
+        const int64_t row = ((int64_t)out_row * (p.hkv * p.group) + hq) * p.ksplit + g_split;
+        float* po = p.ws_o + row * kHD;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                *reinterpret_cast<float4*>(po + d * 32 + 8 * rr + 4 * h) =
+                    make_float4(o[d][4 * rr], o[d][4 * rr + 1], o[d][4 * rr + 2], o[d][4 * rr + 3]);
+        if (h == 0) *reinterpret_cast<float2*>(p.ws_ml + row * 2) = make_float2(my_nkt > 0 ? m : kNegBigE, l);
+        return;
+    }
     const float inv = 1.0f / l;
     uint16_t* op = p.out + out_row * p.out_stride + hq * kHD;
 #pragma unroll
@@ -572,6 +605,30 @@ __global__ __launch_bounds__(kPlanThreads) void extend_plan_kernel(const int32_t
     plan_sort_descending(bs * tiles_per_req, key_tiles, plan, bins, part);
 }
 
+// Joins the key runs of a split launch: one wave per (token, head), lane l owns output columns 2l and 2l + 1.
+__global__ __launch_bounds__(256) void extend_merge_kernel(const float* __restrict__ ws_o, const float* __restrict__ ws_ml, uint16_t* __restrict__ out,
+                                                           int64_t out_stride, int64_t rows, int Hq, int ksplit) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (token, head)
+    if (r >= rows * Hq) return;
+    const int64_t tok = r / Hq;
+    const int hq = (int)(r - tok * Hq);
+    float M = kNegBigE;
+    for (int s = 0; s < ksplit; ++s) M = fmaxf(M, ws_ml[(r * ksplit + s) * 2]);
+    float L = 0.f, o0 = 0.f, o1 = 0.f;
+    for (int s = 0; s < ksplit; ++s) {
+        const float2 ml = *reinterpret_cast<const float2*>(ws_ml + (r * ksplit + s) * 2);
+        if (ml.x <= 0.5f * kNegBigE) continue;  // an empty run: its output slots were never written
+        const float f = fast_exp2(ml.x - M);
+        const float2 o = *reinterpret_cast<const float2*>(ws_o + (r * ksplit + s) * kHD + 2 * lane);
+        L += f * ml.y;
+        o0 += f * o.x;
+        o1 += f * o.y;
+    }
+    const float inv = 1.0f / L;
+    *reinterpret_cast<uint32_t*>(out + tok * out_stride + hq * kHD + 2 * lane) = pack_bf16(o0 * inv, o1 * inv);
+}
+
 template <int NH, int ST, bool GROUPED = false>
 static int launch_extend(const ExtendParams& p, int64_t blocks, hipStream_t stream, const GroupedParams& gp = GroupedParams()) {
     constexpr int kLds = ST * kTileBytes;
@@ -592,11 +649,19 @@ static int launch_extend(const ExtendParams& p, int64_t blocks, hipStream_t stre
 
 using namespace msgl;
 
+constexpr int kMaxKeySplit = 8;
+
+extern "C" size_t msgl_paged_extend_workspace_bytes(int64_t total_tokens, int Hq, int D) {
+    if (total_tokens <= 0 || Hq <= 0 || D <= 0) return 0;
+    return (size_t)total_tokens * Hq * kMaxKeySplit * (D + 2) * sizeof(float);
+}
+
 extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
                                  int64_t cache_stride, const int32_t* req_to_token, int64_t r2t_stride,
                                  const int32_t* req_pool_indices, const int32_t* cu_seqlens_q, const int32_t* prefix_lens,
                                  void* out, int64_t out_stride, int bs, int max_seqlen_q, int max_seqlen_k, const int32_t* plan,
-                                 int Hq, int Hkv, int D, int page_size, float scale, void* stream) {
+                                 int Hq, int Hkv, int D, int page_size, float scale, void* workspace, size_t workspace_bytes,
+                                 int64_t total_tokens, void* stream) {
     (void)page_size;  // the table is read per token, which is valid for every page size
     if (bs == 0 || max_seqlen_q == 0) return MSGL_OK;
     MSGL_REQUIRE(bs > 0 && max_seqlen_q > 0 && max_seqlen_k >= 0, "msgl_paged_extend: bs=%d max_seqlen_q=%d max_seqlen_k=%d", bs,
@@ -631,11 +696,35 @@ extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_
     p.group = Hq / Hkv;
     p.scale_log2e = scale * 1.4426950408889634f;
     p.plan = plan;
-    // query heads per work group: 2 share the staged K/V tile; 1 when that would leave compute units without a block
+    p.ksplit = 1;
+    p.ws_o = nullptr, p.ws_ml = nullptr;
+    // query heads per work group: 2 share the staged K/V tile and give every SIMD two waves
     int nh = (p.group % 2 == 0) ? 2 : 1;
-    if (const char* e = getenv("MSGL_EXTEND_NH")) nh = (atoi(e) == 2 && p.group % 2 == 0) ? 2 : 1;
-    else if (nh == 2 && (int64_t)bs * p.tiles_per_req * (Hq / 2) <= device_cus()) nh = 1;
-    const int64_t gx = (int64_t)bs * p.tiles_per_req * (Hq / nh);
+    const char* nhe = getenv("MSGL_EXTEND_NH");
+    if (nhe) nh = (atoi(nhe) == 2 && p.group % 2 == 0) ? 2 : 1;
+    // Few work items with long key ranges (a short prompt on a long cached prefix, few heads per GPU): with a workspace
+    // the key tiles of every item are cut into runs until the launch covers the chip; without one, one head per group
+    // doubles the number of groups instead (one wave per SIMD: about a fifth slower per group).
+    const int64_t items = (int64_t)bs * p.tiles_per_req * (Hq / nh);
+    const int cus = device_cus();
+    const bool want_split = max_seqlen_k >= 2048 && items < cus;
+    if (want_split && workspace != nullptr && total_tokens > 0) {
+        MSGL_REQUIRE(aligned16(workspace), "msgl_paged_extend: workspace must be 16-byte aligned");
+        const size_t per_split = (size_t)total_tokens * Hq * (D + 2) * sizeof(float);
+        int ks = (int)((cus + items - 1) / items);
+        const int by_keys = (max_seqlen_k / kBN) / 8;  // at least eight key tiles per run
+        ks = ks > kMaxKeySplit ? kMaxKeySplit : ks;
+        ks = ks > by_keys ? by_keys : ks;
+        if (const char* e = getenv("MSGL_EXTEND_KSPLIT")) ks = atoi(e) < 1 ? 1 : (atoi(e) > kMaxKeySplit ? kMaxKeySplit : atoi(e));
+        if ((size_t)ks * per_split > workspace_bytes) ks = (int)(workspace_bytes / per_split);
+        if (ks > 1) {
+            p.ksplit = ks;
+            p.ws_o = static_cast<float*>(workspace);
+            p.ws_ml = p.ws_o + (size_t)total_tokens * Hq * ks * D;
+        }
+    }
+    if (p.ksplit == 1 && !nhe && nh == 2 && items <= cus) nh = 1;
+    const int64_t gx = (int64_t)bs * p.tiles_per_req * (Hq / nh) * p.ksplit;
     MSGL_REQUIRE(gx <= 0x7fffffff, "msgl_paged_extend: grid too large");
     // Requests of at most a dozen key tiles never reach the steady state the three-slot ring is built for; two
     // work groups per CU (two-slot ring, one head per group) overlap their start-up phases instead.
@@ -643,11 +732,17 @@ extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_
     const bool two_slots = se ? atoi(se) == 2 : (max_seqlen_k > 0 && max_seqlen_k <= kShortKv);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (two_slots) {
+        p.ksplit = 1;
         const int64_t g1 = (int64_t)bs * p.tiles_per_req * Hq;
         MSGL_REQUIRE(g1 <= 0x7fffffff, "msgl_paged_extend: grid too large");
         return launch_extend<1, 2>(p, g1, st);
     }
-    return nh == 2 ? launch_extend<2, 3>(p, gx, st) : launch_extend<1, 3>(p, gx, st);
+    const int rc = nh == 2 ? launch_extend<2, 3>(p, gx, st) : launch_extend<1, 3>(p, gx, st);
+    if (rc || p.ksplit == 1) return rc;
+    const int64_t rows = total_tokens * Hq;
+    hipLaunchKernelGGL(extend_merge_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p.ws_o, p.ws_ml, p.out, p.out_stride, total_tokens, Hq,
+                       p.ksplit);
+    return check_launch("extend_merge_kernel");
 }
 
 extern "C" int64_t msgl_extend_plan_items(int bs, int max_seqlen_q) {
@@ -712,6 +807,7 @@ extern "C" int msgl_shared_prefix_decode(const void* q, int64_t q_stride, const 
     p.bs = bs;
     p.hkv = Hkv;
     p.group = Hq / Hkv;
+    p.ksplit = 1;
     p.scale_log2e = scale * 1.4426950408889634f;
     GroupedParams g = {};
     g.first = group_first, g.count = group_count, g.prefix = group_prefix, g.members = group_members;

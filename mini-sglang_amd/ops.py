@@ -376,10 +376,12 @@ def paged_extend(
     out: Optional[torch.Tensor] = None,
     max_seqlen_k: int = 0,
     plan: Optional[torch.Tensor] = None,
+    workspace: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """Extend attention for packed q [sum Sq, Hq, D]; K/V of the new tokens must already be stored.
     `max_seqlen_k` (longest prefix + new tokens, 0 = unknown) and `plan` (from extend_plan, same batch) only
-    steer scheduling; the output does not depend on them."""
+    steer scheduling; the output does not depend on them.  `workspace` (extend_workspace_bytes(T, Hq, D) bytes,
+    optional) lets a launch of few work items over long key ranges split the keys between work groups."""
     _dev_bf16(q, "q")
     _dev_i32(req_pool_indices, "req_pool_indices"), _dev_i32(cu_seqlens_q, "cu_seqlens_q"), _dev_i32(prefix_lens, "prefix_lens")
     _need(q.dim() == 3 and q.stride(2) == 1 and q.stride(1) == q.shape[2], "q must be [T, Hq, D] with dense heads")
@@ -401,12 +403,20 @@ def paged_extend(
     if plan is not None:
         _dev_i32(plan, "plan")
         _need(plan.numel() == extend_plan_items(bs, int(max_seqlen_q)), "plan was made for another bs / max_seqlen_q")
+    if workspace is not None:
+        _need(workspace.is_cuda and workspace.is_contiguous() and workspace.data_ptr() % 16 == 0, "workspace must be a contiguous GPU tensor")
     _check(_lib.msgl_paged_extend(
         q.data_ptr(), qs, k_cache.data_ptr(), v_cache.data_ptr(), cs,
         req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(), cu_seqlens_q.data_ptr(),
         prefix_lens.data_ptr(), out.data_ptr(), os_, bs, int(max_seqlen_q), int(max_seqlen_k),
-        plan.data_ptr() if plan is not None else None, Hq, Hkv, D, page_size, float(scale), _stream()))
+        plan.data_ptr() if plan is not None else None, Hq, Hkv, D, page_size, float(scale),
+        workspace.data_ptr() if workspace is not None else None,
+        workspace.numel() * workspace.element_size() if workspace is not None else 0, T, _stream()))
     return out
+
+
+def extend_workspace_bytes(total_tokens: int, Hq: int, D: int) -> int:
+    return int(_lib.msgl_paged_extend_workspace_bytes(int(total_tokens), Hq, D))
 
 
 def extend_plan_items(bs: int, max_seqlen_q: int) -> int:

@@ -300,14 +300,14 @@ def build_extend_case(Hq, Hkv, page_size, prefix_lens, input_lens, seed):
                 prefix=torch.tensor(prefix_lens, dtype=torch.int32), inp=torch.tensor(input_lens, dtype=torch.int32))
 
 
-def run_extend(case, page_size, max_seqlen_k=0, planned=False):
+def run_extend(case, page_size, max_seqlen_k=0, planned=False, workspace=None):
     ops = _ops()
     kvd = case["kv"].to(DEV)
     cu = torch.nn.functional.pad(torch.cumsum(case["inp"], 0, dtype=torch.int32), (1, 0)).to(DEV)
     plan = ops.extend_plan(cu, case["prefix"].to(DEV), int(case["inp"].max())) if planned else None
     out = ops.paged_extend(case["q"].to(DEV), kvd[:, 0], kvd[:, 1], case["r2t"].to(DEV), case["req_idx"].to(DEV), cu,
                            case["prefix"].to(DEV), int(case["inp"].max()), 128 ** -0.5, page_size, max_seqlen_k=max_seqlen_k,
-                           plan=plan)
+                           plan=plan, workspace=workspace)
     torch.cuda.synchronize()
     return out.cpu()
 
@@ -357,6 +357,29 @@ def test_extend_few_queries_on_long_unaligned_prefixes(heads_per_group, monkeypa
     monkeypatch.setenv("MSGL_EXTEND_NH", str(heads_per_group))
     case = build_extend_case(8, 2, 1, [4097, 33, 63, 64, 0], [1, 5, 2, 1, 1], seed=41)
     check_extend(case, run_extend(case, 1))
+
+
+@pytest.mark.parametrize("Hq,Hkv,forced", [(8, 1, None), (8, 1, "3"), (2, 1, None), (4, 4, "2")])
+def test_extend_key_split_matches_unsplit_and_oracle(Hq, Hkv, forced, monkeypatch):
+    """Few work items over long key ranges: with a workspace the keys of every item are cut into runs, one work group
+    each, and joined by a second kernel.  Compared with the oracle and with the unsplit launch (which sums the same
+    products in another order: fp32 rounding only).  Covers runs that end before a row's first visible key, runs
+    that are empty for the early query tiles, prefixes that are no multiple of a key tile, and ragged batches."""
+    ops = _ops()
+    if forced:
+        monkeypatch.setenv("MSGL_EXTEND_KSPLIT", forced)
+    ps = 16
+    prefix, inputs = [2048 + 16 * 3, 0, 4096], [200, 2300, 1]
+    case = build_extend_case(Hq, Hkv, ps, prefix, inputs, seed=61 + Hq)
+    plain = run_extend(case, ps, max_seqlen_k=max(p + n for p, n in zip(prefix, inputs)))
+    check_extend(case, plain)
+    T = sum(inputs)
+    ws = torch.empty(ops.extend_workspace_bytes(T, Hq, 128), dtype=torch.uint8, device=DEV)
+    ws.view(torch.float32).fill_(float("nan"))  # a partial that is read without having been written shows
+    for planned in (False, True):
+        split = run_extend(case, ps, max_seqlen_k=max(p + n for p, n in zip(prefix, inputs)), planned=planned, workspace=ws)
+        check_extend(case, split)
+        assert (split.float() - plain.float()).abs().max().item() <= 1e-2
 
 
 @pytest.mark.parametrize("Hq,Hkv", [(16, 8), (32, 8), (8, 1), (4, 4)])
