@@ -94,13 +94,20 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, kv, kv_elems, (uint64_t)1);
     hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, q, q_elems, (uint64_t)2);
     CK(hipDeviceSynchronize());
+    // key-split workspace, as a caller hands it over when the launch has fewer work items than compute units
+    void* d_ws = nullptr;
+    size_t ws_bytes = 0;
+    if ((int64_t)bs * ((sq + 127) / 128) * std::max(1, hq / 2) < 256 && prefix + sq >= 2048) {
+        ws_bytes = msgl_paged_extend_workspace_bytes((int64_t)bs * sq, hq, D);
+        CK(hipMalloc(&d_ws, ws_bytes));
+    }
 
     hipStream_t st;
     CK(hipStreamCreate(&st));
     auto step = [&]() {
         const int rc = msgl_paged_extend(q, (int64_t)hq * D, kv, kv + row, cache_stride, d_r2t, max_ctx, d_idx, d_cu, d_pre, out,
-                                         (int64_t)hq * D, bs, sq, /*max_seqlen_k=*/0, /*plan=*/nullptr, hq, hkv, D, ps,
-                                         0.08838834764831845f, st);
+                                         (int64_t)hq * D, bs, sq, /*max_seqlen_k=*/prefix + sq, /*plan=*/nullptr, hq, hkv, D, ps,
+                                         0.08838834764831845f, d_ws, ws_bytes, (int64_t)bs * sq, st);
         if (rc != 0) {
             fprintf(stderr, "msgl_paged_extend: %d %s\n", rc, msgl_last_error());
             exit(1);
