@@ -513,16 +513,18 @@ __global__ __launch_bounds__(256) void paged_decode_merge_small_kernel(DecodePar
     *reinterpret_cast<uint32_t*>(p.out + (int64_t)b * p.out_stride + hq * kD + d) = pack_bf16(o0 * inv, o1 * inv);
 }
 
-int launch_decode_mfma(const DecodeParams& p, int Hkv, hipStream_t stream);  // paged_decode_mfma.hip
+int launch_decode_mfma(const DecodeParams& p, int G, int Hkv, hipStream_t stream);  // paged_decode_mfma.hip
 
-// 8 query heads per kv head on 16-slot runs take the matrix-core kernel (MSGL_DECODE_G8=gather: the vector one)
-static bool use_mfma_decode(int G, int page_size) {
-    if (G != 8 || page_size % kTile != 0) return false;
-    static const bool gather = [] {
-        const char* e = getenv("MSGL_DECODE_G8");
-        return e && e[0] == 'g';
-    }();
-    return !gather;
+// Which decode calls on 16-slot runs take the matrix-core kernel.  8 query heads per kv head: always (the vector kernel
+// is bound by its arithmetic there).  MSGL_DECODE_MFMA overrides for measurements: "0" never, "8" G = 8 only,
+// "4" G = 4 too, "4s" G = 4 only for ranks with one or two kv heads.
+static bool use_mfma_decode(int G, int Hkv, int page_size) {
+    if (page_size % kTile != 0 || (G != 8 && G != 4)) return false;
+    const char* e = getenv("MSGL_DECODE_MFMA");
+    if (e && e[0] == '0') return false;
+    if (G == 8) return true;
+    if (e && e[0] == '4') return e[1] != 's' || Hkv <= 2;
+    return false;
 }
 
 template <int G, int HPB>
@@ -530,8 +532,8 @@ static int launch_decode(const DecodeParams& p, int page_size, hipStream_t strea
     const dim3 grid(p.bs * p.max_splits), block(kWaves * 64);
     const size_t lds = (size_t)kWaves * G * (kD + 2) * sizeof(float);
     int rc;
-    if (use_mfma_decode(G, page_size)) {
-        rc = launch_decode_mfma(p, HPB, stream);
+    if (use_mfma_decode(G, HPB, page_size)) {
+        rc = launch_decode_mfma(p, G, HPB, stream);
     } else {
         if (page_size % kTile == 0)
             hipLaunchKernelGGL((paged_decode_kernel<G, HPB, true>), grid, block, lds, stream, p);

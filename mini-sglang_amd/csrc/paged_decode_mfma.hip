@@ -31,7 +31,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 mbf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short mshort4_t;
 typedef __attribute__((ext_vector_type(4))) float mf32x4_t;
 
-constexpr int kMG = 8;                  // query heads per kv head
 constexpr int kMKSlots = 2;             // K tiles (16 rows of 256 B = 4 KiB) a wave holds: one being read, the others on their way
 constexpr int kMVSlots = 2;             // V tiles
 constexpr int kMHalf = 4096;            // bytes of a K or V tile
@@ -91,9 +90,11 @@ __device__ __forceinline__ float max_over_lane_groups(float x) {
     return fmaxf(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1]));
 }
 
-template <int HPB>
+// G = query heads per kv head (any count up to 16 fits the 16 padded columns; built for 8 and, for ranks with one or two
+// kv heads, 4), HPB = local kv heads.
+template <int G, int HPB>
 __global__ __launch_bounds__(kWaves * 64) void paged_decode_mfma_kernel(DecodeParams p) {
-    constexpr int G = kMG;
+    static_assert(G <= 16, "the query heads of a kv head are the 16 columns of S^T");
     constexpr int WPH = kWaves / HPB;  // waves sharing one kv head
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -285,30 +286,39 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_mfma_kernel(DecodePa
     merge_waves_and_store<G, WPH>(p, lds_o, lds_ml, h, lane, b, split, nsplit == 1 && si.extra == 0);
 }
 
-template <int HPB>
+template <int G, int HPB>
 static int launch_mfma(const DecodeParams& p, hipStream_t stream) {
     static bool configured = false;  // the rings need more than the 64 KiB a kernel gets by default
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(paged_decode_mfma_kernel<HPB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(paged_decode_mfma_kernel<G, HPB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kMLdsBytes) != hipSuccess) {
             set_error("msgl_paged_decode: cannot reserve %d bytes of LDS", kMLdsBytes);
             return MSGL_E_LAUNCH;
         }
         configured = true;
     }
-    hipLaunchKernelGGL(paged_decode_mfma_kernel<HPB>, dim3(p.bs * p.max_splits), dim3(kWaves * 64), kMLdsBytes, stream, p);
+    hipLaunchKernelGGL((paged_decode_mfma_kernel<G, HPB>), dim3(p.bs * p.max_splits), dim3(kWaves * 64), kMLdsBytes, stream, p);
     return check_launch("paged_decode_mfma_kernel");
 }
 
-// The main launch of a decode call with 8 query heads per kv head and 16-slot runs; the caller launches the merge.
-int launch_decode_mfma(const DecodeParams& p, int Hkv, hipStream_t stream) {
-    switch (Hkv) {
-        case 1: return launch_mfma<1>(p, stream);
-        case 2: return launch_mfma<2>(p, stream);
-        case 4: return launch_mfma<4>(p, stream);
-        case 8: return launch_mfma<8>(p, stream);
+// The main launch of a decode call on 16-slot runs through the matrix-core kernel; the caller launches the merge.
+int launch_decode_mfma(const DecodeParams& p, int G, int Hkv, hipStream_t stream) {
+    if (G == 8) {
+        switch (Hkv) {
+            case 1: return launch_mfma<8, 1>(p, stream);
+            case 2: return launch_mfma<8, 2>(p, stream);
+            case 4: return launch_mfma<8, 4>(p, stream);
+            case 8: return launch_mfma<8, 8>(p, stream);
+        }
+    } else if (G == 4) {
+        switch (Hkv) {
+            case 1: return launch_mfma<4, 1>(p, stream);
+            case 2: return launch_mfma<4, 2>(p, stream);
+            case 4: return launch_mfma<4, 4>(p, stream);
+            case 8: return launch_mfma<4, 8>(p, stream);
+        }
     }
-    set_error("msgl_paged_decode: Hkv=%d unsupported (1, 2, 4 or 8 local kv heads)", Hkv);
+    set_error("msgl_paged_decode: matrix-core kernel has no build for %d query heads per kv head x %d kv heads", G, Hkv);
     return MSGL_E_INVALID;
 }
 

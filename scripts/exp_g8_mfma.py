@@ -3,7 +3,7 @@ import sys, os, subprocess, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) < 2:
     for mode in ("mfma", "gather"):
-        env = dict(os.environ, MSGL_DECODE_G8=mode)
+        env = dict(os.environ, MSGL_DECODE_MFMA=("8" if mode == "mfma" else "0"))
         subprocess.run([sys.executable, "-u", __file__, mode], env=env, check=False)
     sys.exit(0)
 import torch
