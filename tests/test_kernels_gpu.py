@@ -264,6 +264,25 @@ def test_decode_planned_launch_is_bit_identical(Hq, Hkv, page_size):
         assert torch.equal(run_decode(case, page_size, max_splits=max_splits, chunk_tokens=ch, plan=plan), base)
 
 
+@pytest.mark.parametrize("Hq,Hkv,page_size", [(32, 8, 16), (4, 1, 64), (8, 2, 16), (16, 4, 32)])
+def test_decode_four_heads_per_kv_head_on_the_matrix_core_kernel(Hq, Hkv, page_size, monkeypatch):
+    """The matrix-core decode kernel is built for 4 query heads per kv head as well (a measurement override; by default
+    only 8 heads per kv head take it): same results as the gather kernel to fp32 / bf16 rounding, and within the bound
+    of the oracle, over splits, a launch plan and the cache-policy hint."""
+    ops = _ops()
+    seq = [1, 15, 16, 17, 100, 1023, 1024, 2500, 4097]
+    case = build_case(Hq, Hkv, page_size, seq, seed=91 + Hq)
+    plan = ops.decode_plan(case["seq_lens"].to(DEV), 16, 272)
+    reuse = torch.tensor([0, 0, 16, 16, 64, 512, 0, 1024, 4096], dtype=torch.int32, device=DEV)
+    for kw in (dict(), dict(max_splits=16, chunk_tokens=272), dict(max_splits=16, chunk_tokens=272, plan=plan, reuse_lens=reuse)):
+        monkeypatch.setenv("MSGL_DECODE_MFMA", "0")
+        gather = run_decode(case, page_size, **kw)
+        monkeypatch.setenv("MSGL_DECODE_MFMA", "4")
+        mfma = run_decode(case, page_size, **kw)
+        check_decode(case, mfma)
+        assert (mfma.float() - gather.float()).abs().max().item() <= 8e-3
+
+
 def test_decode_long_context_split():
     case = build_case(8, 1, 64, [20000, 3], seed=9)
     check_decode(case, run_decode(case, 64, max_splits=128, chunk_tokens=256))
