@@ -157,7 +157,38 @@ __device__ __forceinline__ void stage_write(char* tile, int skey, int c16, const
     }
 }
 
-constexpr int SG_VALU = 0x002, SG_MFMA = 0x008, SG_VMEMREAD = 0x020, SG_DSREAD = 0x100, SG_DSWRITE = 0x200, SG_TRANS = 0x400;
+// Diagnostic build only (-DEXT_STAMPS, see tools/extend_bench.hip): cycle stamps around the segments of the steady-state
+// loop, summed over two waves of every work group.  Each stamp drains the LDS queue, so the segment times are upper
+// bounds; no stamp exists in the library build.
+#ifdef EXT_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(i)                                                             \
+    do {                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        unsigned long long t_;                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        acc_[i] += t_ - last_;                                               \
+        last_ = t_;                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+// one key of a thread's share at a time, for callers that spread the staging over their matrix work
+template <int KSTEP, int KPT>
+__device__ __forceinline__ void stage_write_one(char* tile, int skey, int c16, const StageRegs<KPT>& r, int i) {
+    *reinterpret_cast<u32x4_t*>(tile + skey * kKRow + ((c16 ^ (skey & 15)) << 4) + i * KSTEP * kKRow) = r.k[i];
+    *reinterpret_cast<u32x4_t*>(tile + kKBytes + skey * kVRow + (c16 << 4) + i * KSTEP * kVRow) = r.v[i];
+}
+template <int KPT>
+__device__ __forceinline__ void stage_load_one(const uint16_t* kcol, const uint16_t* vcol, uint32_t cache_stride, const StageSlots<KPT>& sl,
+                                               StageRegs<KPT>& r, int i) {
+    const uint64_t o = (uint64_t)sl.s[i] * cache_stride;
+    r.k[i] = *reinterpret_cast<const u32x4_t*>(kcol + o);
+    r.v[i] = *reinterpret_cast<const u32x4_t*>(vcol + o);
+}
+
+constexpr int SG_VALU = 0x002, SG_MFMA = 0x008, SG_TRANS = 0x400;
 
 // ST = LDS ring depth.  3: one barrier per tile, 108 KiB, one work group per CU — the throughput form.
 // 2: the ring slot of tile t+1 is only free once every wave has finished tile t-1, so the write sits between two
@@ -320,6 +351,14 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
             vf[d].hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(vp + d * 64 + 8 * kVRow));
         }
     };
+    auto v_half = [&](int tile, int s, int d0, short8_t (&vf)[4]) {  // output blocks d0, d0 + 1 of the same
+        const char* vp = lds + tile + v_lane + 16 * s * kVRow;
+#pragma unroll
+        for (int d = d0; d < d0 + 2; ++d) {
+            vf[d].lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(vp + d * 64));
+            vf[d].hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(vp + d * 64 + 8 * kVRow));
+        }
+    };
     auto pv_step = [&](int s, const short8_t (&vf)[4]) {
 #pragma unroll
         for (int d = 0; d < 4; ++d)
@@ -430,39 +469,51 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
     // first loop at different t; both loops have one barrier per iteration, so the counts agree.
     int t = 0;
     // ---- steady state: tile t+1 is visible to every row of the wave ----
+#ifdef EXT_STAMPS
+    unsigned long long acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+    int iters_ = 0;
+#endif
     for (; t + 1 < full_nkt; ++t) {
+        STAMP(0);
         stage_step(t);
+        STAMP(1);
         rescale_o(alpha_pend);  // a branch of its own, ahead of the block below, so that nothing of that block sinks behind it
-        stage_refill(t);
 
-        // S^T of tile t+1 (reads two k-steps ahead of the matrix instructions), the row sum of tile t beside it
+        // S^T of tile t+1, ordered by hand in eight slices (one per k-step, fenced from each other): the K fragments of
+        // k-step ks + 2 are requested before the matrix instructions of k-step ks, and the row sum of tile t, the
+        // ring-slot writes of tile t+2, the loads of tile t+3 and the first V^T fragments of tile t fill the slices.
         f32x16_t s0, s1;
         short8_t vf[4], vg[4];
-        qk_tile(nxt, s0, s1);
-        v_step(cur, 0, vf);
-        l = l * alpha_pend + sum_tile();
-        __builtin_amdgcn_sched_group_barrier(SG_DSREAD, 6, 0);
+        uint4 ka[3][2];
+        const uint32_t kp = nxt + k_lane;
+        auto k_read = [&](int ks) {
+            const char* a = lds + (kp ^ (uint32_t)(ks << 5));
+            ka[ks % 3][0] = *reinterpret_cast<const uint4*>(a);
+            ka[ks % 3][1] = *reinterpret_cast<const uint4*>(a + 32 * kKRow);
+        };
+        k_read(0);
+        k_read(1);
 #pragma unroll
-        for (int i = 0; i < 2 * KPT; ++i) {  // the ring-slot writes of tile t+2 ...
-            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(SG_DSREAD, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(SG_VALU, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(SG_DSWRITE, 1, 0);
-        }
+        for (int r = 0; r < 16; ++r) s0[r] = 0.f, s1[r] = 0.f;
+        float part[4];
 #pragma unroll
-        for (int i = 2 * KPT; i < 10; ++i) {  // ... then the loads of tile t+3
-            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(SG_DSREAD, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(SG_VALU, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(SG_VMEMREAD, 1, 0);
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks + 2 < 8) k_read(ks + 2);
+            if (ks < 4) part[ks] = sum_step(pf[ks], 0.f);
+            if (ks == 4) l = l * alpha_pend + ((part[0] + part[2]) + (part[1] + part[3]));
+            if (ks < KPT) {
+                if constexpr (ST == 3) stage_write_one<KSTEP>(lds + nn, skey, c16, stg, ks);
+            } else if (ks < 2 * KPT) {
+                stage_load_one(kcol, vcol, p.cache_stride, slots, stg, ks - KPT);
+            }
+            if (ks == min(2 * KPT, 7)) slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + ST + 1, nkt - 1), skey, kv_len);
+            if (ks >= 6) v_half(cur, 0, 2 * (ks - 6), vf);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ka[ks % 3][0]), as_bf16x8(qf[ks]), s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ka[ks % 3][1]), as_bf16x8(qf[ks]), s1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int i = 10; i < 14; ++i) {
-            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(SG_DSREAD, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(SG_VALU, 3, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        STAMP(2);
         float st[32];
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = s0[r], st[16 + r] = s1[r];
@@ -478,6 +529,7 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
                           st[min(r + 7, 30)]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP(3);
         const float mn = fmaxf(m, max_with_lane_xor32(fmaxf(mx, st[31])) * p.scale_log2e);
         alpha_pend = fast_exp2(m - mn);
         m = mn;
@@ -493,6 +545,7 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
             __builtin_amdgcn_sched_group_barrier(SG_TRANS, 3, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(4);
         // k-step 2 beside the next 12
         v_step(cur, 3, vg);
         pv_step(2, vf);
@@ -505,6 +558,7 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
             __builtin_amdgcn_sched_group_barrier(SG_TRANS, 3, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(5);
         // k-step 3 beside the last 8
         pv_step(3, vg);
         exp_range(st, 24, 32, mn);
@@ -519,7 +573,17 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
         __builtin_amdgcn_sched_barrier(0);
         pf[3] = n3;
         advance_ring();
+        STAMP(6);
+#ifdef EXT_STAMPS
+        ++iters_;
+#endif
     }
+#ifdef EXT_STAMPS
+    if (lane == 0 && (wave == 0 || wave == 5)) {
+        for (int i = 0; i < 10; ++i) atomicAdd(&g_stamps[i], acc_[i]);
+        atomicAdd(&g_stamps[15], (unsigned long long)iters_);
+    }
+#endif
     // ---- the diagonal tiles, then the tiles only other waves of the work group still need ----
     for (; t < nkt; ++t) {
         stage_step(t);
@@ -651,6 +715,15 @@ using namespace msgl;
 
 constexpr int kMaxKeySplit = 8;
 
+#ifdef EXT_STAMPS
+extern "C" void msgl_extend_stamps(unsigned long long* out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(msgl::g_stamps), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(msgl::g_stamps), z, sizeof(z));
+    }
+}
+#endif
 extern "C" size_t msgl_paged_extend_workspace_bytes(int64_t total_tokens, int Hq, int D) {
     if (total_tokens <= 0 || Hq <= 0 || D <= 0) return 0;
     return (size_t)total_tokens * Hq * kMaxKeySplit * (D + 2) * sizeof(float);

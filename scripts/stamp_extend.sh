@@ -1,0 +1,19 @@
+#!/bin/bash
+# Cycle anatomy of the prefill kernel's steady-state loop: builds the kernel and the standalone driver with -DEXT_STAMPS
+# (in-kernel cycle stamps per segment) into tools/ko/ and prints where the cycles go.  Build here, run on the GPU box:
+#   scripts/stamp_extend.sh build && gpurun -- scripts/stamp_extend.sh run
+set -e
+cd "$(dirname "$0")/.."
+C=mini-sglang_amd/csrc
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-value -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1"
+if [ "$1" = build ]; then
+    mkdir -p tools/ko
+    make -C $C >/dev/null
+    /opt/rocm/bin/hipcc $FLAGS -DEXT_STAMPS -c $C/paged_extend.hip -o /tmp/pe_stamps.o
+    /opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 -DEXT_STAMPS -c tools/extend_bench.hip -o /tmp/eb_stamps.o
+    OBJS=$(ls $C/*.o | grep -v paged_extend.o)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/eb_stamps.o /tmp/pe_stamps.o $OBJS -o tools/ko/extend_stamps
+else
+    timeout -k 10 120 tools/ko/extend_stamps --bs 2 --sq 16384 --steps 5 --warmup 2
+    MSGL_EXTEND_NH=1 timeout -k 10 120 tools/ko/extend_stamps --bs 2 --sq 16384 --steps 5 --warmup 2
+fi

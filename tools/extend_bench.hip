@@ -1,6 +1,9 @@
 // Standalone driver for msgl_paged_extend: bs equal-length prompts over a scattered page table, random
 // bf16 pool, HIP-event timing.  Used for profiler passes (rocprofv3 --pmc) without a Python process.
 //
+// Built with -DEXT_STAMPS against a library object built the same way it also prints the cycles the steady-state
+// loop of the prefill kernel spends per segment (see scripts/stamp_extend.sh).
+//
 //   extend_bench [--bs 2] [--sq 8192] [--prefix 0] [--ps 16] [--hq 32] [--hkv 8] [--steps 10] [--warmup 2]
 #include <hip/hip_runtime.h>
 
@@ -15,6 +18,9 @@
 
 #include "../include/msgl_hip.h"
 
+#ifdef EXT_STAMPS
+extern "C" void msgl_extend_stamps(unsigned long long* out, int reset);
+#endif
 #define CK(x)                                                                                  \
     do {                                                                                       \
         hipError_t e_ = (x);                                                                   \
@@ -128,5 +134,18 @@ int main(int argc, char** argv) {
     printf("{\"bs\": %d, \"sq\": %d, \"prefix\": %d, \"ps\": %d, \"hq\": %d, \"hkv\": %d, \"ms_per_step\": %.4f, \"TFLOPs\": %.1f, "
            "\"flops_per_step\": %.0f}\n",
            bs, sq, prefix, ps, hq, hkv, ms / steps, flops / (ms / steps * 1e-3) / 1e12, flops);
+#ifdef EXT_STAMPS
+    {
+        unsigned long long st_[16];
+        msgl_extend_stamps(st_, 0);
+        const double it = (double)st_[15];
+        printf("steady iterations sampled: %.0f; cycles per iteration by segment:\n", it);
+        const char* names[7] = {"loop edge", "barrier", "rescale+QK(t+1)+staging", "PV0+max", "PV1+exp12", "PV2+exp12", "PV3+exp8+pack"};
+        double tot = 0;
+        for (int i = 0; i < 7; ++i) tot += st_[i] / it;
+        for (int i = 0; i < 7; ++i) printf("  %-22s %8.1f\n", names[i], st_[i] / it);
+        printf("  %-22s %8.1f\n", "total", tot);
+    }
+#endif
     return 0;
 }
