@@ -83,11 +83,15 @@ __device__ __forceinline__ void wait_dma_groups(int groups) {
 // max over the four lanes that hold the same query head (lane, lane ^ 16, lane ^ 32, lane ^ 48)
 __device__ __forceinline__ float max_over_lane_groups(float x) {
     unsigned u = __builtin_bit_cast(unsigned, x);
-    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    x = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
+    // (results through scalars: a bit cast applied straight to an element of the result vector reads element 0
+    // whichever element is named)
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned a0 = a[0], a1 = a[1];
+    x = fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1));
     u = __builtin_bit_cast(unsigned, x);
-    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned b0 = b[0], b1 = b[1];
+    return fmaxf(__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1));
 }
 
 // G = query heads per kv head (any count up to 16 fits the 16 padded columns; built for 8 and, for ranks with one or two

@@ -283,6 +283,26 @@ def test_decode_four_heads_per_kv_head_on_the_matrix_core_kernel(Hq, Hkv, page_s
         assert (mfma.float() - gather.float()).abs().max().item() <= 8e-3
 
 
+@pytest.mark.parametrize("Hq,Hkv", [(64, 8), (32, 8), (8, 1), (4, 4)])
+def test_decode_scores_that_grow_along_the_keys(Hq, Hkv):
+    """Online-softmax bookkeeping of the decode kernels (gather kernel, matrix-core kernel for 8 heads per kv head,
+    their split merge) under running maxima that jump by hundreds of units: K rows in bands of 512 positions scaled by
+    1, 12, 1, 40, 90.  A maximum that misses part of the keys would leave probabilities far above 1 and overflow."""
+    ps = 16
+    seq = [300, 1200, 2500, 2560]
+    case = build_case(Hq, Hkv, ps, seq, seed=123 + Hq)
+    kv = case["kv_full"].float()
+    for b, S in enumerate(seq):
+        for band, f in enumerate([1.0, 12.0, 1.0, 40.0, 90.0]):
+            lo, hi = band * 512, min((band + 1) * 512, S)
+            if lo < hi:
+                kv[case["r2t"][int(case["req_idx"][b]), lo:hi].long(), 0] *= f
+    kv = kv.to(torch.bfloat16)
+    case["kv_full"], case["k_cache"], case["v_cache"] = kv, kv[:, 0], kv[:, 1]
+    for kw in (dict(), dict(max_splits=8, chunk_tokens=256)):
+        check_decode(case, run_decode(case, ps, **kw))
+
+
 def test_decode_long_context_split():
     case = build_case(8, 1, 64, [20000, 3], seed=9)
     check_decode(case, run_decode(case, 64, max_splits=128, chunk_tokens=256))
@@ -348,12 +368,22 @@ def check_extend(case, out):
         start += n
 
 
-@pytest.mark.parametrize("heads_per_group", [1, 2])
+EXTEND_FORMS = ["one-head", "two-heads-four-waves", "two-heads-eight-waves"]
+
+
+def _force_extend_form(monkeypatch, form):
+    """The work-group shapes of the three-slot extend kernel: one query head per group (4 waves), two heads per group as
+    4 waves that own both heads each (the default for an even number of heads per kv head), or as 8 waves that own one
+    head each.  The library reads the overrides per call."""
+    monkeypatch.setenv("MSGL_EXTEND_NH", "1" if form == "one-head" else "2")
+    monkeypatch.setenv("MSGL_EXTEND_WIDE", "0" if form == "two-heads-eight-waves" else "1")
+
+
+@pytest.mark.parametrize("form", EXTEND_FORMS)
 @pytest.mark.parametrize("Hq,Hkv", [(16, 8), (32, 8), (8, 1), (4, 4)])
 @pytest.mark.parametrize("page_size", [1, 16, 64])
-def test_extend(Hq, Hkv, page_size, heads_per_group, monkeypatch):
-    # both work-group shapes of the kernel (one or two query heads per group); the library reads the override per call
-    monkeypatch.setenv("MSGL_EXTEND_NH", str(heads_per_group))
+def test_extend(Hq, Hkv, page_size, form, monkeypatch):
+    _force_extend_form(monkeypatch, form)
     ps = page_size
     prefix = [0, 0, ps * 2, 0, 64 * ps // ps * (ps if ps > 1 else 1), 0]
     prefix = [p - p % ps for p in prefix]
@@ -362,18 +392,38 @@ def test_extend(Hq, Hkv, page_size, heads_per_group, monkeypatch):
     check_extend(case, run_extend(case, ps))
 
 
-@pytest.mark.parametrize("heads_per_group", [1, 2])
-def test_extend_long_prefix(heads_per_group, monkeypatch):
-    monkeypatch.setenv("MSGL_EXTEND_NH", str(heads_per_group))
+@pytest.mark.parametrize("form", EXTEND_FORMS)
+def test_extend_long_prefix(form, monkeypatch):
+    _force_extend_form(monkeypatch, form)
     case = build_extend_case(16, 8, 16, [2048, 0], [130, 700], seed=21)
     check_extend(case, run_extend(case, 16))
 
 
-@pytest.mark.parametrize("heads_per_group", [1, 2])
-def test_extend_few_queries_on_long_unaligned_prefixes(heads_per_group, monkeypatch):
+@pytest.mark.parametrize("form", EXTEND_FORMS)
+def test_extend_scores_that_grow_along_the_keys(form, monkeypatch):
+    """Online-softmax bookkeeping under a running maximum that keeps moving: the keys come in bands of 256 positions
+    whose rows are scaled by 1, 3, 1, 14, 1, 40, 80, so the row maxima jump by a few units (below the growth at which
+    the four-wave kernel moves its reference maximum: probabilities above 1), by tens of units (every kernel rescales
+    its output accumulators in the middle of its steady state), and again inside the rows' own causal range."""
+    _force_extend_form(monkeypatch, form)
+    ps = 16
+    prefix, inputs = [1536, 256 + 32], [384, 300]
+    case = build_extend_case(8, 2, ps, prefix, inputs, seed=77)
+    kv = case["kv"].float()
+    for b in range(2):
+        for band, f in enumerate([1.0, 3.0, 1.0, 14.0, 1.0, 40.0, 80.0]):
+            lo, hi = band * 256, min((band + 1) * 256, int(case["seq_lens"][b]))
+            if lo < hi:
+                kv[case["r2t"][b, lo:hi].long(), 0] *= f
+    case["kv"] = kv.to(torch.bfloat16)
+    check_extend(case, run_extend(case, ps))
+
+
+@pytest.mark.parametrize("form", EXTEND_FORMS)
+def test_extend_few_queries_on_long_unaligned_prefixes(form, monkeypatch):
     """Decode-like calls through the extend entry point (chunked prefill tails): 1-5 new tokens on prefixes that are
     not multiples of the 64-key tile, so almost every wave of the work group has nothing to do."""
-    monkeypatch.setenv("MSGL_EXTEND_NH", str(heads_per_group))
+    _force_extend_form(monkeypatch, form)
     case = build_extend_case(8, 2, 1, [4097, 33, 63, 64, 0], [1, 5, 2, 1, 1], seed=41)
     check_extend(case, run_extend(case, 1))
 
@@ -403,10 +453,12 @@ def test_extend_key_split_matches_unsplit_and_oracle(Hq, Hkv, forced, monkeypatc
 
 @pytest.mark.parametrize("Hq,Hkv", [(16, 8), (32, 8), (8, 1), (4, 4)])
 @pytest.mark.parametrize("page_size", [1, 16])
-def test_extend_short_requests_two_slot_kernel(Hq, Hkv, page_size):
+def test_extend_short_requests_two_slot_kernel(Hq, Hkv, page_size, monkeypatch):
     """With the longest request announced (max_seqlen_k) and short, the library takes the kernel with a two-slot
-    ring and one head per work group; 0 (unknown) takes the three-slot one.  Same oracle, same bar, and the two
-    kernels agree to the last bit (same arithmetic in the same order, only the staging differs)."""
+    ring and one head per work group; 0 (unknown) takes a three-slot one.  Same oracle, same bar.  The two-slot and
+    the eight-wave three-slot kernel agree to the last bit (same arithmetic in the same order, only the staging
+    differs); the four-wave three-slot kernel (two heads per wave, the default for an even number of heads per kv
+    head) lets a row's reference maximum lag behind its running maximum, so it agrees to rounding."""
     ps = page_size
     prefix = [0, 0, 2 * ps, 0, 16 * ps if ps > 1 else 64, 0, 448]
     inputs = [1, 31, 33, 128, 200, 300, 320]
@@ -415,6 +467,10 @@ def test_extend_short_requests_two_slot_kernel(Hq, Hkv, page_size):
     assert kmax <= 768
     out = run_extend(case, ps, max_seqlen_k=kmax)
     check_extend(case, out)
+    wide = run_extend(case, ps, max_seqlen_k=0)
+    check_extend(case, wide)
+    assert (wide.float() - out.float()).abs().max().item() <= 1e-2
+    monkeypatch.setenv("MSGL_EXTEND_WIDE", "0")
     assert torch.equal(out, run_extend(case, ps, max_seqlen_k=0))
 
 

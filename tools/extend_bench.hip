@@ -20,6 +20,7 @@
 
 #ifdef EXT_STAMPS
 extern "C" void msgl_extend_stamps(unsigned long long* out, int reset);
+extern "C" void msgl_extend_wide_stamps(unsigned long long* out);
 #endif
 #define CK(x)                                                                                  \
     do {                                                                                       \
@@ -138,12 +139,14 @@ int main(int argc, char** argv) {
     {
         unsigned long long st_[16];
         msgl_extend_stamps(st_, 0);
+        if (st_[15] == 0) msgl_extend_wide_stamps(st_);  // the launch took the one-wave-per-SIMD kernel
         const double it = (double)st_[15];
         printf("steady iterations sampled: %.0f; cycles per iteration by segment:\n", it);
-        const char* names[7] = {"loop edge", "barrier", "rescale+QK(t+1)+staging", "PV0+max", "PV1+exp12", "PV2+exp12", "PV3+exp8+pack"};
+        const char* names[9] = {"loop edge", "barrier", "rescale+QK(t+1)+staging", "PV0+max", "PV1+exp12", "PV2+exp12", "PV3+exp8+pack",
+                                "(wide) QK slice 0", "(wide) QK slices 1-3"};
         double tot = 0;
-        for (int i = 0; i < 7; ++i) tot += st_[i] / it;
-        for (int i = 0; i < 7; ++i) printf("  %-22s %8.1f\n", names[i], st_[i] / it);
+        for (int i = 0; i < 9; ++i) tot += st_[i] / it;
+        for (int i = 0; i < 9; ++i) printf("  %-22s %8.1f\n", names[i], st_[i] / it);
         printf("  %-22s %8.1f\n", "total", tot);
     }
 #endif
