@@ -22,6 +22,7 @@ constexpr int kTileBytes = kBN * kKRow + kBN * kVRow;
 
 constexpr float kNegBigE = -1.0e30f;
 constexpr int kShortKv = 768;     // longest request (prefix + new tokens) that still takes the two-slot kernel
+constexpr int kWideMinKv = 1536;  // longest request for which the eight-wave kernel is preferred to the four-wave one
 
 struct ExtendParams {
     const uint16_t* q;

@@ -63,8 +63,8 @@ for cfg in "p16k --bs 1 --sq 16384 --prefix 0 --ps 16 --hq 32 --hkv 8" "tp8_4k_o
   tail -1 $OUT/ext_${name}_trace.log | tee -a $SUM
   stats $OUT/ext_${name}_trace
   timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $OUT/ext_${name}_p1 -- ./tools/extend_bench "$@" --steps 2 --warmup 1 > $OUT/ext_${name}_p1.log 2>&1 || say "p1 failed"
-  counters $OUT/ext_${name}_p1 paged_extend_kernel
+  counters $OUT/ext_${name}_p1 paged_extend
   timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/ext_${name}_p2 -- ./tools/extend_bench "$@" --steps 2 --warmup 1 > $OUT/ext_${name}_p2.log 2>&1 || say "p2 failed"
-  counters $OUT/ext_${name}_p2 paged_extend_kernel
+  counters $OUT/ext_${name}_p2 paged_extend
 done
 say "done"
