@@ -12,6 +12,23 @@ namespace msgl {
 // ---- host side -------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+
+// Kernel attributes (an LDS size beyond the default 64 KiB) belong to a (kernel, device) pair: every launch site keeps
+// one of these and configures its kernel the first time it launches on a device.  Two threads racing on that first
+// launch both configure, which is harmless; the bit is set only after success.
+struct PerDeviceOnce {
+    unsigned long long done[4] = {0, 0, 0, 0};  // devices 0..255
+    template <typename F>
+    bool ensure(F&& configure) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 255) return configure();
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (__atomic_load_n(&done[dev >> 6], __ATOMIC_ACQUIRE) & bit) return true;
+        if (!configure()) return false;
+        __atomic_fetch_or(&done[dev >> 6], bit, __ATOMIC_RELEASE);
+        return true;
+    }
+};
 int device_cus();
 
 #define MSGL_REQUIRE(cond, ...)            \

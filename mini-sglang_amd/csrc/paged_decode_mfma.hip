@@ -292,14 +292,13 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_mfma_kernel(DecodePa
 
 template <int G, int HPB>
 static int launch_mfma(const DecodeParams& p, hipStream_t stream) {
-    static bool configured = false;  // the rings need more than the 64 KiB a kernel gets by default
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(paged_decode_mfma_kernel<G, HPB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kMLdsBytes) != hipSuccess) {
-            set_error("msgl_paged_decode: cannot reserve %d bytes of LDS", kMLdsBytes);
-            return MSGL_E_LAUNCH;
-        }
-        configured = true;
+    static PerDeviceOnce once;  // the rings need more than the 64 KiB a kernel gets by default
+    if (!once.ensure([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(paged_decode_mfma_kernel<G, HPB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMLdsBytes) == hipSuccess;
+        })) {
+        set_error("msgl_paged_decode: cannot reserve %d bytes of LDS", kMLdsBytes);
+        return MSGL_E_LAUNCH;
     }
     hipLaunchKernelGGL((paged_decode_mfma_kernel<G, HPB>), dim3(p.bs * p.max_splits), dim3(kWaves * 64), kMLdsBytes, stream, p);
     return check_launch("paged_decode_mfma_kernel");

@@ -535,14 +535,13 @@ __global__ __launch_bounds__(256) void extend_merge_kernel(const float* __restri
 template <int NH, int ST, bool GROUPED = false>
 static int launch_extend(const ExtendParams& p, int64_t blocks, hipStream_t stream, const GroupedParams& gp = GroupedParams()) {
     constexpr int kLds = ST * kTileBytes;
-    static bool configured = false;  // the ring is larger than the 64 KiB a kernel gets by default
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(paged_extend_kernel<NH, ST, GROUPED>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kLds) != hipSuccess) {
-            set_error("msgl_paged_extend: cannot reserve %d bytes of LDS", kLds);
-            return MSGL_E_LAUNCH;
-        }
-        configured = true;
+    static PerDeviceOnce once;  // the ring is larger than the 64 KiB a kernel gets by default
+    if (!once.ensure([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(paged_extend_kernel<NH, ST, GROUPED>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
+        })) {
+        set_error("msgl_paged_extend: cannot reserve %d bytes of LDS", kLds);
+        return MSGL_E_LAUNCH;
     }
     hipLaunchKernelGGL((paged_extend_kernel<NH, ST, GROUPED>), dim3((unsigned)blocks), dim3(256 * NH), kLds, stream, p, gp);
     return check_launch("paged_extend_kernel");

@@ -450,14 +450,13 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
 
 int launch_extend_wide(const ExtendParams& p, int64_t blocks, hipStream_t stream) {
     constexpr int kLds = 3 * kTileBytes;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(paged_extend_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) !=
-            hipSuccess) {
-            set_error("msgl_paged_extend: cannot reserve %d bytes of LDS", kLds);
-            return MSGL_E_LAUNCH;
-        }
-        configured = true;
+    static PerDeviceOnce once;
+    if (!once.ensure([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(paged_extend_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kLds) == hipSuccess;
+        })) {
+        set_error("msgl_paged_extend: cannot reserve %d bytes of LDS", kLds);
+        return MSGL_E_LAUNCH;
     }
     hipLaunchKernelGGL(paged_extend_wide_kernel, dim3((unsigned)blocks), dim3(256), kLds, stream, p);
     return check_launch("paged_extend_wide_kernel");
