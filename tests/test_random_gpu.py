@@ -58,7 +58,7 @@ def test_decode_shared_prefix_random_case(seed):
 
 
 @pytest.mark.parametrize("seed", range(20 + MORE))
-def test_extend_random_case(seed):
+def test_extend_random_case(seed, monkeypatch):
     rng = random.Random(3000 + seed)
     Hq, Hkv = rng.choice([(32, 8), (16, 8), (8, 1), (4, 1), (4, 4), (16, 4)])
     ps = rng.choice([1, 16, 64])
@@ -69,4 +69,11 @@ def test_extend_random_case(seed):
     base = tk.run_extend(case, ps)
     tk.check_extend(case, base)
     kmax = max(p + n for p, n in zip(prefix, inputs))
-    assert torch.equal(tk.run_extend(case, ps, max_seqlen_k=kmax, planned=True), base)
+    # The hints (longest request, launch plan) choose among kernels and launch orders, never results: the two-slot and
+    # the eight-wave kernel do the same arithmetic in the same order (equal to the last bit); the four-wave kernel, the
+    # default for long or unannounced key ranges, lets a row's reference maximum lag, so it agrees to rounding.
+    hinted = tk.run_extend(case, ps, max_seqlen_k=kmax, planned=True)
+    tk.check_extend(case, hinted)
+    assert (hinted.float() - base.float()).abs().max().item() <= 1e-2
+    monkeypatch.setenv("MSGL_EXTEND_WIDE", "0")
+    assert torch.equal(tk.run_extend(case, ps, max_seqlen_k=kmax, planned=True), tk.run_extend(case, ps))
