@@ -336,6 +336,20 @@ def recorded_traffic(layout, bs, S, ps, Hq, Hkv):
             "traffic_measured_at_commit": rec.get("commit")}
 
 
+def recorded_extend_counters(prompt, prefix, ps, Hq, Hkv):
+    """Matrix-core busy fraction of the extend launch from the committed profiler record (profiles/extend_counters.json,
+    written by scripts/profile_r02.sh), when it was taken on this shape; counters cannot be read inside a timed run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "extend_counters.json")) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return {}
+    if rec.get("shape") != {"prompt": prompt, "prefix": prefix, "page_size": ps, "hq": Hq, "hkv": Hkv}:
+        return {}
+    return {"matrix_core_busy": rec.get("matrix_core_busy"), "matrix_core_busy_source": "profiles/extend_counters.json: " + rec.get("how", ""),
+            "matrix_core_busy_measured_at_commit": rec.get("commit"), "kernel": rec.get("kernel")}
+
+
 def other_decode_configs(args, world, rank):
     """Decode attention (one layer per launch, same accounting as the headline: algorithmic KV bytes, no
     de-duplication of shared prefixes) on the other single-layer shapes the benchmark family names: Qwen3-0.6B
@@ -486,6 +500,7 @@ def extend_attention(args, world, rank):
 
     try:
         res = measure(args.hq // world, args.hkv // world, args.page_size, 16384, 0)
+        res["roofline"].update(recorded_extend_counters(16384, 0, args.page_size, args.hq // world, args.hkv // world))
         if world == 1:  # the long-context configuration's prefill: one TP-8 shard of Qwen3-32B (8 q / 1 kv head), page_size 64
             res["qwen3_32b_tp8_shard"] = [measure(8, 1, 64, 16384, 0), measure(8, 1, 64, 4096, 65536, steps=6)]
         return res

@@ -67,4 +67,22 @@ for cfg in "p16k --bs 1 --sq 16384 --prefix 0 --ps 16 --hq 32 --hkv 8" "tp8_4k_o
   timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/ext_${name}_p2 -- ./tools/extend_bench "$@" --steps 2 --warmup 1 > $OUT/ext_${name}_p2.log 2>&1 || say "p2 failed"
   counters $OUT/ext_${name}_p2 paged_extend
 done
+# matrix-core busy fraction of the 16k-prompt extend launch, as a record bench.py attaches to its extend figure
+python3 - "$OUT/ext_p16k_p2" "${MSGL_COMMIT:-unknown}" <<'PY' | tee -a $SUM
+import collections, csv, glob, json, sys
+acc = collections.defaultdict(list); kernel = None
+for f in glob.glob(sys.argv[1] + "/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "paged_extend" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"])); kernel = r["Kernel_Name"].split("(")[0]
+if acc:
+    mean = {k: sum(v[1:]) / max(1, len(v) - 1) if len(v) > 1 else v[0] for k, v in acc.items()}
+    rec = {"shape": {"prompt": 16384, "prefix": 0, "page_size": 16, "hq": 32, "hkv": 8}, "kernel": kernel,
+           "matrix_core_busy": round(mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * mean["SQ_BUSY_CU_CYCLES"]), 4),
+           "mfma_instructions": round(mean["SQ_INSTS_MFMA"]), "lds_bank_conflict_cycles": round(mean["SQ_LDS_BANK_CONFLICT"]),
+           "how": "rocprofv3 --pmc (one pass, no trace) on tools/extend_bench: SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES), mean per dispatch after the first",
+           "commit": sys.argv[2]}
+    json.dump(rec, open("gpurun_out/extend_counters.json", "w"), indent=1)
+    print("  extend counters record:", json.dumps(rec))
+PY
 say "done"
