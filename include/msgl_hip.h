@@ -201,7 +201,8 @@ int msgl_shared_prefix_decode(const void* q, int64_t q_stride,
  * FA3 metadata (fa3_attn_backend.py:43-82), or 0 when the caller does not know
  * it.  plan: NULL, or the launch order msgl_extend_plan wrote for these very
  * cu_seqlens_q / prefix_lens / max_seqlen_q.  Both only steer scheduling (kernel
- * variant, block order); the output does not depend on them.
+ * variant, block order): the plan never changes a bit of the output, the kernel
+ * variants agree to rounding (they order their sums and rescalings differently).
  * The new tokens' K/V must already be in the pool (msgl_store_kv first), as in
  * torch_attn_backend.py:195-196.
  * ------------------------------------------------------------------------- */
