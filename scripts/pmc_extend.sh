@@ -19,7 +19,7 @@ for name in ("p1","p2"):
     if not fs: print(name,"no csv"); continue
     acc=collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if "paged_extend_kernel" in r["Kernel_Name"]:
+        if "paged_extend" in r["Kernel_Name"] and "merge" not in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             regs=(r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"))
     print(name, regs, {k: round(sum(v)/len(v)) for k,v in acc.items()})
