@@ -35,7 +35,6 @@ constexpr int kMKSlots = 2;             // K tiles (16 rows of 256 B = 4 KiB) a 
 constexpr int kMVSlots = 2;             // V tiles
 constexpr int kMHalf = 4096;            // bytes of a K or V tile
 constexpr int kMWaveBytes = (kMKSlots + kMVSlots) * kMHalf;   // (three K slots, 20 KiB a wave, measured 3-5 % slower than two)
-constexpr int kMLdsBytes = kWaves * kMWaveBytes;
 
 // Four LDS-DMA loads of 4 rows x 256 B each into 4 KiB at LDS byte address `dst`; lane offsets off[i] (bytes from
 // `base`) select the row and the swizzled chunk.  The statement first waits for the wave's outstanding LDS reads (the
@@ -96,10 +95,10 @@ __device__ __forceinline__ float max_over_lane_groups(float x) {
 
 // G = query heads per kv head (any count up to 16 fits the 16 padded columns; built for 8 and, for ranks with one or two
 // kv heads, 4), HPB = local kv heads.
-template <int G, int HPB>
-__global__ __launch_bounds__(kWaves * 64) void paged_decode_mfma_kernel(DecodeParams p) {
+template <int G, int HPB, int NW = kWaves>
+__global__ __launch_bounds__(NW * 64) void paged_decode_mfma_kernel(DecodeParams p) {
     static_assert(G <= 16, "the query heads of a kv head are the 16 columns of S^T");
-    constexpr int WPH = kWaves / HPB;  // waves sharing one kv head
+    constexpr int WPH = NW / HPB;  // waves sharing one kv head
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
     int item = blockIdx.x;
@@ -274,8 +273,8 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_mfma_kernel(DecodePa
     // exchange area of the merge
     wait_dma_groups(0);
     __syncthreads();
-    float* lds_o = reinterpret_cast<float*>(smem);       // [kWaves][G][128]
-    float* lds_ml = lds_o + kWaves * G * kD;              // [kWaves][G][2]
+    float* lds_o = reinterpret_cast<float*>(smem);       // [NW][G][128]
+    float* lds_ml = lds_o + NW * G * kD;                  // [NW][G][2]
     if (qn < G) {
         float* dst = lds_o + (wave * G + qn) * kD + 4 * g4;
 #pragma unroll
@@ -290,17 +289,18 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_mfma_kernel(DecodePa
     merge_waves_and_store<G, WPH>(p, lds_o, lds_ml, h, lane, b, split, nsplit == 1 && si.extra == 0);
 }
 
-template <int G, int HPB>
+template <int G, int HPB, int NW = kWaves>
 static int launch_mfma(const DecodeParams& p, hipStream_t stream) {
+    constexpr int kLds = NW * kMWaveBytes;
     static PerDeviceOnce once;  // the rings need more than the 64 KiB a kernel gets by default
     if (!once.ensure([] {
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(paged_decode_mfma_kernel<G, HPB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMLdsBytes) == hipSuccess;
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(paged_decode_mfma_kernel<G, HPB, NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
         })) {
-        set_error("msgl_paged_decode: cannot reserve %d bytes of LDS", kMLdsBytes);
+        set_error("msgl_paged_decode: cannot reserve %d bytes of LDS", kLds);
         return MSGL_E_LAUNCH;
     }
-    hipLaunchKernelGGL((paged_decode_mfma_kernel<G, HPB>), dim3(p.bs * p.max_splits), dim3(kWaves * 64), kMLdsBytes, stream, p);
+    hipLaunchKernelGGL((paged_decode_mfma_kernel<G, HPB, NW>), dim3(p.bs * p.max_splits), dim3(NW * 64), kLds, stream, p);
     return check_launch("paged_decode_mfma_kernel");
 }
 
@@ -308,8 +308,18 @@ static int launch_mfma(const DecodeParams& p, hipStream_t stream) {
 int launch_decode_mfma(const DecodeParams& p, int G, int Hkv, hipStream_t stream) {
     if (G == 8) {
         switch (Hkv) {
-            case 1: return launch_mfma<8, 1>(p, stream);
-            case 2: return launch_mfma<8, 2>(p, stream);
+            // One or two kv heads per rank, launches of about one work group per CU (long contexts at small batch): 4 waves
+            // per (request, split) instead of 8 -- half the LDS, so two groups fit a CU, and half the waves to merge at
+            // the end.  Measured at 128k contexts: one kv head 7 % faster at batch 1, 6 % at 2, 1-3 % at 4-8, equal at 16;
+            // two kv heads 6 % at batch 1, 2 % at 4, 3 % SLOWER at 16.  MSGL_DECODE_MFMA_NW = 4 / 8 forces either.
+            case 1:
+            case 2: {
+                const char* e = getenv("MSGL_DECODE_MFMA_NW");
+                const int64_t grid = (int64_t)p.bs * p.max_splits, cus = device_cus();
+                const bool four = e ? atoi(e) == 4 : grid <= (Hkv == 1 ? 2 * cus : cus);
+                if (Hkv == 1) return four ? launch_mfma<8, 1, 4>(p, stream) : launch_mfma<8, 1>(p, stream);
+                return four ? launch_mfma<8, 2, 4>(p, stream) : launch_mfma<8, 2>(p, stream);
+            }
             case 4: return launch_mfma<8, 4>(p, stream);
             case 8: return launch_mfma<8, 8>(p, stream);
         }

@@ -303,6 +303,21 @@ def test_decode_scores_that_grow_along_the_keys(Hq, Hkv):
         check_decode(case, run_decode(case, ps, **kw))
 
 
+@pytest.mark.parametrize("waves", ["4", "8"])
+@pytest.mark.parametrize("Hq,Hkv", [(8, 1), (16, 2)])
+def test_decode_matrix_core_kernel_with_four_and_eight_waves(Hq, Hkv, waves, monkeypatch):
+    """The matrix-core decode kernel runs a (request, split) with 8 waves, or with 4 for one or two kv heads per rank on
+    launches of about one work group per compute unit; the override forces either on the same cases (ragged lengths,
+    splits, a launch plan, page sizes 16 and 64)."""
+    ops = _ops()
+    monkeypatch.setenv("MSGL_DECODE_MFMA_NW", waves)
+    for ps, seq in ((16, [1, 15, 16, 17, 100, 1023, 1024, 2500, 4097]), (64, [5000, 64, 65, 8191])):
+        case = build_case(Hq, Hkv, ps, seq, seed=211 + Hq + ps)
+        plan = ops.decode_plan(case["seq_lens"].to(DEV), 16, 272)
+        for kw in (dict(), dict(max_splits=16, chunk_tokens=272), dict(max_splits=16, chunk_tokens=272, plan=plan)):
+            check_decode(case, run_decode(case, ps, **kw))
+
+
 def test_decode_long_context_split():
     case = build_case(8, 1, 64, [20000, 3], seed=9)
     check_decode(case, run_decode(case, 64, max_splits=128, chunk_tokens=256))
