@@ -22,9 +22,10 @@ constexpr float kLazyLog2 = 10.0f;  // growth of a row's running maximum (log2 d
 // compiled in their all-VGPR form, so that the softmax reads S^T without copies; O^T is touched by nothing but these
 // instructions, the rare rescale and the epilogue, and 128 registers of it would not fit beside S^T otherwise).
 // The compiler does not know that this statement is a matrix instruction: whoever reads the accumulator with anything
-// else than this statement waits out the matrix pipe first (drain_matrix_pipe).
+// else than this statement waits out the matrix pipe first (drain_matrix_pipe).  Volatile, so that it keeps its place
+// relative to that wait (volatile statements are not reordered among themselves).
 __device__ __forceinline__ void mfma_into_agpr(f32x16_t& acc, const u32x4_t a, const u32x4_t b) {
-    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 // (every accumulator then passes through an empty statement of its own behind the wait: volatile statements keep their
 // order, so no read of an accumulator can be moved in front of the wait)
