@@ -21,7 +21,7 @@ constexpr int kKBytes = kBN * kKRow;
 constexpr int kTileBytes = kBN * kKRow + kBN * kVRow;
 
 constexpr float kNegBigE = -1.0e30f;
-constexpr int kShortKv = 768;     // longest request (prefix + new tokens) that still takes the two-slot kernel
+constexpr int kShortKv = 1024;    // longest request (prefix + new tokens) that still takes the two-slot kernel
 constexpr int kWideMinKv = 1536;  // longest request for which the eight-wave kernel is preferred to the four-wave one
 
 struct ExtendParams {
