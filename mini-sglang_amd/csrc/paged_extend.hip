@@ -212,9 +212,12 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
         }
     };
     auto row_max = [&](const float (&st)[32]) {
-        float mx = max3_raw(st[0], st[1], st[2]);
+        // (compiler-visible max: this path reads the accumulators right behind the matrix instructions that write
+        // them, and only for instructions it knows does the compiler insert the wait that takes; the hand-written
+        // max3 chains of the steady-state loop sit several matrix instructions behind theirs)
+        float mx = fmaxf(fmaxf(st[0], st[1]), st[2]);
 #pragma unroll
-        for (int r = 3; r < 31; r += 2) mx = max3_raw(mx, st[r], st[r + 1]);
+        for (int r = 3; r < 31; r += 2) mx = fmaxf(fmaxf(mx, st[r]), st[r + 1]);
         return max_with_lane_xor32(fmaxf(mx, st[31]));
     };
     auto exp_range = [&](float (&st)[32], int lo, int hi, float mn) {
