@@ -19,6 +19,8 @@
 // placed between them, so the vector and matrix pipes run side by side.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "extend_common.h"
 #include "plan_sort.h"
 
@@ -316,7 +318,10 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
     int iters_ = 0;
 #endif
-    for (; t + 1 < full_nkt; ++t) {
+    // One pipelined iteration: S^T and softmax of tile t+1 beside O^T of tile t.  MASKED: tile t+1 lies on the wave's
+    // diagonal, its scores pass through the causal mask first (64 more vector instructions, not overlapped).
+    auto pipelined = [&](auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         STAMP(0);
         stage_step(t);
         STAMP(1);
@@ -359,6 +364,7 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
         float st[32];
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = s0[r], st[16 + r] = s1[r];
+        if constexpr (MASKED) mask_scores(st, (t + 1) * kBN);
         // O^T of tile t, k-step by k-step (the consumed P^T registers free up for the new ones), with the
         // softmax of tile t+1 in its shadow.  k-step 0 beside the row max (asm max3: ordered by hand).
         v_step(cur, 1, vg);
@@ -419,14 +425,18 @@ __global__ __launch_bounds__(256 * NH, 2) void paged_extend_kernel(ExtendParams 
 #ifdef EXT_STAMPS
         ++iters_;
 #endif
-    }
+    
+    };
+    for (; t + 1 < full_nkt; ++t) pipelined(std::false_type{});
+    // ---- the wave's diagonal tiles, same pipeline with the mask ----
+    for (; t + 1 < my_nkt; ++t) pipelined(std::true_type{});
 #ifdef EXT_STAMPS
     if (lane == 0 && (wave == 0 || wave == 5)) {
         for (int i = 0; i < 7; ++i) atomicAdd(&g_stamps[i], acc_[i]);
         atomicAdd(&g_stamps[15], (unsigned long long)iters_);
     }
 #endif
-    // ---- the diagonal tiles, then the tiles only other waves of the work group still need ----
+    // ---- the wave's last tile, then the tiles only other waves of the work group still need ----
     for (; t < nkt; ++t) {
         stage_step(t);
         stage_refill(t);  // past the last tile: a copy of it into a free slot
