@@ -516,15 +516,18 @@ __global__ __launch_bounds__(256) void paged_decode_merge_small_kernel(DecodePar
 int launch_decode_mfma(const DecodeParams& p, int G, int Hkv, hipStream_t stream);  // paged_decode_mfma.hip
 
 // Which decode calls on 16-slot runs take the matrix-core kernel.  8 query heads per kv head: always (the vector kernel
-// is bound by its arithmetic there).  MSGL_DECODE_MFMA overrides for measurements: "0" never, "8" G = 8 only,
-// "4" G = 4 too, "4s" G = 4 only for ranks with one or two kv heads.
+// is bound by its arithmetic there).  4 heads per kv head: ranks with 2 or 4 kv heads (TP 4 / 2 shards of a 32 q / 8 kv
+// model), where it measures 1-4 % ahead of the gather kernel at every batch size tried; with 8 kv heads the two tie and
+// with one the gather kernel is 4 % ahead on large batches.  MSGL_DECODE_MFMA overrides for measurements: "0" never,
+// "8" G = 8 only, "4" G = 4 always, "4s" G = 4 only for ranks with one or two kv heads.
 static bool use_mfma_decode(int G, int Hkv, int page_size) {
     if (page_size % kTile != 0 || (G != 8 && G != 4)) return false;
     const char* e = getenv("MSGL_DECODE_MFMA");
     if (e && e[0] == '0') return false;
     if (G == 8) return true;
+    if (e && e[0] == '8') return false;
     if (e && e[0] == '4') return e[1] != 's' || Hkv <= 2;
-    return false;
+    return Hkv == 2 || Hkv == 4;
 }
 
 template <int G, int HPB>
