@@ -517,17 +517,18 @@ int launch_decode_mfma(const DecodeParams& p, int G, int Hkv, hipStream_t stream
 
 // Which decode calls on 16-slot runs take the matrix-core kernel.  8 query heads per kv head: always (the vector kernel
 // is bound by its arithmetic there).  4 heads per kv head: ranks with 2 or 4 kv heads (TP 4 / 2 shards of a 32 q / 8 kv
-// model), where it measures 1-4 % ahead of the gather kernel at every batch size tried; with 8 kv heads the two tie and
-// with one the gather kernel is 4 % ahead on large batches.  MSGL_DECODE_MFMA overrides for measurements: "0" never,
-// "8" G = 8 only, "4" G = 4 always, "4s" G = 4 only for ranks with one or two kv heads.
-static bool use_mfma_decode(int G, int Hkv, int page_size) {
+// model), where it measures 1-4 % ahead of the gather kernel at every batch size tried, and ranks with one kv head
+// (2-11 % ahead, most at small batches) unless the launch has a single split per request (256 requests x 8192 tokens,
+// one group each: the gather kernel is 3 % ahead); with 8 kv heads the two tie.  MSGL_DECODE_MFMA overrides for
+// measurements: "0" never, "8" G = 8 only, "4" G = 4 always, "4s" G = 4 only for ranks with one or two kv heads.
+static bool use_mfma_decode(int G, int Hkv, int page_size, int max_splits) {
     if (page_size % kTile != 0 || (G != 8 && G != 4)) return false;
     const char* e = getenv("MSGL_DECODE_MFMA");
     if (e && e[0] == '0') return false;
     if (G == 8) return true;
     if (e && e[0] == '8') return false;
     if (e && e[0] == '4') return e[1] != 's' || Hkv <= 2;
-    return Hkv == 2 || Hkv == 4;
+    return Hkv == 2 || Hkv == 4 || (Hkv == 1 && max_splits > 1);
 }
 
 template <int G, int HPB>
@@ -535,7 +536,7 @@ static int launch_decode(const DecodeParams& p, int page_size, hipStream_t strea
     const dim3 grid(p.bs * p.max_splits), block(kWaves * 64);
     const size_t lds = (size_t)kWaves * G * (kD + 2) * sizeof(float);
     int rc;
-    if (use_mfma_decode(G, HPB, page_size)) {
+    if (use_mfma_decode(G, HPB, page_size, p.max_splits)) {
         rc = launch_decode_mfma(p, G, HPB, stream);
     } else {
         if (page_size % kTile == 0)

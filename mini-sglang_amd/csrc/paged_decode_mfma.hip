@@ -325,7 +325,10 @@ int launch_decode_mfma(const DecodeParams& p, int G, int Hkv, hipStream_t stream
         }
     } else if (G == 4) {
         switch (Hkv) {
-            case 1: return launch_mfma<4, 1>(p, stream);
+            case 1: {  // 4 waves per group: 1-2 % ahead of 8 at every shape tried
+                const char* e = getenv("MSGL_DECODE_MFMA_NW");
+                return (e && atoi(e) == 8) ? launch_mfma<4, 1>(p, stream) : launch_mfma<4, 1, 4>(p, stream);
+            }
             case 2: return launch_mfma<4, 2>(p, stream);
             case 4: return launch_mfma<4, 4>(p, stream);
             case 8: return launch_mfma<4, 8>(p, stream);
