@@ -16,7 +16,10 @@ namespace msgl {
 #ifdef EXT_STAMPS
 __device__ unsigned long long g_stamps_wide[16];
 #endif
-constexpr float kLazyLog2 = 10.0f;  // growth of a row's running maximum (log2 domain) that moves its reference maximum
+// Largest sum of one lane's 32 probabilities of a tile that the steady-state loop accepts without looking at the
+// scores' maximum: probabilities are taken relative to a reference maximum that only moves when this bound is crossed
+// (2^21 keeps every probability below 2^21: as exact in bf16 as one below 1, and far from any f32 overflow).
+constexpr float kTileSumLimit = 2097152.0f;
 
 // O^T += A . B with the accumulator in the accumulation half of the register file (the other MFMAs of this file are
 // compiled in their all-VGPR form, so that the softmax reads S^T without copies; O^T is touched by nothing but these
@@ -35,6 +38,14 @@ __device__ __forceinline__ void drain_matrix_pipe(f32x16_t (&o)[2][4]) {
     for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int d = 0; d < 4; ++d) asm volatile("" : "+a"(o[e][d]));
+}
+
+// One v_add_f32 the compiler cannot pair with its neighbour into a v_pk_add_f32: beside matrix instructions the packed
+// form costs more issue time than the two plain adds it replaces.
+__device__ __forceinline__ float add_alone(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams p) {
@@ -110,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
         for (int d = 0; d < 4; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[e][d][r] = 0.f;
-    float m[2] = {kNegBigE, kNegBigE}, l[2] = {0.f, 0.f}, alpha_pend[2] = {1.0f, 1.0f};
+    float m[2] = {kNegBigE, kNegBigE}, l[2] = {0.f, 0.f}, l_before[2] = {0.f, 0.f}, alpha_pend[2] = {1.0f, 1.0f};
     uint4 pf[2][4];
 #pragma unroll
     for (int e = 0; e < 2; ++e)
@@ -200,7 +211,8 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
                 for (int r = 0; r < 16; ++r) o[e][d][r] *= alpha_pend[e];
         }
     };
-    // whole softmax of one head's tile, no overlap (first tile and tiles on the diagonal); leaves the pending factor
+    // whole softmax of one head's tile with its exact maximum, no overlap (first tile, tiles on the diagonal, and a tile
+    // the steady-state loop gave up on); leaves the factor O^T is still owed and the row sum up to date
     auto softmax_tile = [&](int e, const f32x16_t& s0, const f32x16_t& s1, int k0, bool masked) {
         float st[32];
 #pragma unroll
@@ -212,6 +224,7 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
         exp_range(st, 0, 32, mn);
 #pragma unroll
         for (int s = 0; s < 4; ++s) pf[e][s] = pack_step(st, s);
+        l[e] = l[e] * alpha_pend[e] + sum_tile(e);
     };
 
     const int c16 = tid & 15;
@@ -232,7 +245,10 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
         f32x16_t s[2][2];
         qk_tile(0, s);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) softmax_tile(e, s[e][0], s[e][1], 0, full_nkt == 0);
+        for (int e = 0; e < 2; ++e) {
+            softmax_tile(e, s[e][0], s[e][1], 0, full_nkt == 0);
+            alpha_pend[e] = 1.0f;  // O^T is still zero
+        }
     }
 
     int cur = 0, nxt = kTileBytes, nn = 2 * kTileBytes;
@@ -242,10 +258,12 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
     };
     int t = 0;
     // ---- steady state: tile t+1 is visible to every row of the wave ----
-    // The reference maximum m of a row follows its running maximum only when that has grown by more than kLazyLog2
-    // (probabilities up to 2^kLazyLog2 are as exact in bf16 and as harmless in the fp32 sums as those below 1), so a
-    // factor for O^T other than 1 is an event of the first few tiles.  The loop below has no code for it: it stops
-    // after the iteration that produced such a factor, the factor is applied outside, and the loop is entered again.
+    // The loop never looks at the maximum of a tile's scores.  Probabilities are taken relative to the reference maximum
+    // m of the row as it stands (the exact maximum of the last tile that went through softmax_tile); what the loop
+    // watches is each lane's sum of the tile's probabilities.
+    // While that stays under kTileSumLimit nothing can overflow and nothing loses precision, whatever the scores did.
+    // The iteration that crosses the bound is the loop's last: its probabilities are discarded, the tile is redone with
+    // its exact maximum outside (O^T and the row sums rescaled), and the loop is entered again.
 #ifdef EXT_STAMPS
     unsigned long long acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
@@ -255,13 +273,14 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
     // (one basic block: a second exit inside the body would let the compiler sink the softmax arithmetic, whose results
     // are only used an iteration later, behind the matrix instructions it is meant to run beside)
     bool go = t + 1 < full_nkt;
+    bool within = true;
     while (go) {
         STAMP(0);
         __syncthreads();
         STAMP(1);
         // S^T of tile t+1 for both heads in eight fenced slices (one per k-step: the K fragments of k-step ks + 2 are
-        // requested before the four matrix instructions of k-step ks), with the row sums of tile t, the ring-slot writes
-        // of tile t+2, the loads of tile t+3 and the first V^T fragments of tile t in the slices.
+        // requested before the four matrix instructions of k-step ks), with the ring-slot writes of tile t+2, the loads
+        // of tile t+3 and the first V^T fragments of tile t in the slices.
         f32x16_t s[2][2];
         short8_t vf[4], vg[4];
         uint4 ka[3][2];
@@ -277,11 +296,9 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
         for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[e][0][r] = 0.f, s[e][1][r] = 0.f;
-        float part[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             if (ks + 2 < 8) k_read(ks + 2);
-            part[ks] = sum_step(pf[ks >> 2][ks & 3], 0.f);
             if (ks < KPT) stage_write_one<KSTEP>(lds + nn, skey, c16, stg, ks);
             else stage_load_one(kcol, vcol, p.cache_stride, slots, stg, ks - KPT);
             if (ks == 7) slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + ST + 1, nkt - 1), skey, kv_len);
@@ -297,70 +314,53 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
             if (ks == 3) STAMP(8);
 #endif
         }
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-            l[e] += (part[4 * e] + part[4 * e + 2]) + (part[4 * e + 1] + part[4 * e + 3]);  // the pending factor is 1 in here
         STAMP(2);
         float st[2][32];
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[e][r] = s[e][0][r], st[e][16 + r] = s[e][1][r];
-        // O^T of tile t, k-step by k-step, with the softmax of tile t+1 in its shadow.  k-step 0 beside the row maxima.
+        // O^T of tile t: 32 matrix instructions (k-step, output block, head), one fenced slice each, with the softmax of
+        // tile t+1 dealt over the slices: slice g exponentiates element g of either head, adds element g-1 to the lane's
+        // tile sums (two chains per head), and from k-step 1 on packs one pair of the previous k-step's elements into
+        // P^T, whose old value that k-step's matrix instructions have consumed by then.
         v_step(cur, 1, vg);
-        float mx[2];
+        float ts[2][2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) mx[e] = max3_raw(st[e][0], st[e][1], st[e][2]);
+        for (int g = 0; g < 32; ++g) {
+            const int ks = g >> 3, i = g & 7, d = i >> 1, e = i & 1;
+            if (g == 8) v_step(cur, 2, vf);
+            if (g == 16) v_step(cur, 3, vg);
+            mfma_into_agpr(o[e][d], __builtin_bit_cast(u32x4_t, (ks & 1) ? vg[d] : vf[d]), __builtin_bit_cast(u32x4_t, pf[e][ks]));
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const int r = 3 + 8 * d;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                mfma_into_agpr(o[e][d], __builtin_bit_cast(u32x4_t, vf[d]), __builtin_bit_cast(u32x4_t, pf[e][0]));
-                mx[e] = max9_raw(mx[e], st[e][r], st[e][r + 1], st[e][r + 2], st[e][r + 3], st[e][min(r + 4, 30)], st[e][min(r + 5, 30)],
-                                 st[e][min(r + 6, 30)], st[e][min(r + 7, 30)]);
+            for (int he = 0; he < 2; ++he) {
+                st[he][g] = fast_exp2(__builtin_fmaf(st[he][g], p.scale_log2e, -m[he]));
+                if (g == 1 || g == 2) ts[he][(g - 1) & 1] = st[he][g - 1];
+                else if (g > 2) ts[he][(g - 1) & 1] = add_alone(ts[he][(g - 1) & 1], st[he][g - 1]);
+            }
+            if (ks >= 1) {
+                const int he = i >> 2, pr = i & 3, r = 8 * (ks - 1) + 2 * pr;
+                const uint32_t w = pack_bf16(st[he][r], st[he][r + 1]);
+                if (pr == 0) pf[he][ks - 1].x = w;
+                else if (pr == 1) pf[he][ks - 1].y = w;
+                else if (pr == 2) pf[he][ks - 1].z = w;
+                else pf[he][ks - 1].w = w;
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef EXT_STAMPS
+            if (g == 7) STAMP(3);
+            if (g == 15) STAMP(4);
+            if (g == 23) STAMP(5);
+#endif
         }
-        STAMP(3);
-        float mn[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float run = fmaxf(m[e], max_with_lane_xor32(fmaxf(mx[e], st[e][31])) * p.scale_log2e);
-            mn[e] = (run - m[e] > kLazyLog2) ? run : m[e];
-            alpha_pend[e] = fast_exp2(m[e] - mn[e]);
-            m[e] = mn[e];
-        }
-        // k-steps 1..3, eight fenced slices each (one matrix instruction per head and output block), with the exps and
-        // packs of tile t+1 dealt over the slices: elements [0, 12) of either head beside k-step 1 (then P^T of k-step 0,
-        // whose old value k-step 0 has consumed), [12, 24) beside k-step 2, [24, 32) beside k-step 3.
-        auto pv_slices = [&](int ks, const short8_t (&vv)[4], int lo, int per_head) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int d = i >> 1, e = i & 1;
-                mfma_into_agpr(o[e][d], __builtin_bit_cast(u32x4_t, vv[d]), __builtin_bit_cast(u32x4_t, pf[e][ks]));
-                // slice i: elements of head (i >> 2), a quarter of that head's share
-                const int he = i >> 2, q = i & 3, step = per_head / 4;
-                exp_range(st[he], lo + q * step, lo + (q + 1) * step, mn[he]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        v_step(cur, 2, vf);
-        pv_slices(1, vg, 0, 12);
-        STAMP(4);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) pf[e][0] = pack_step(st[e], 0);
-        v_step(cur, 3, vg);
-        pv_slices(2, vf, 12, 12);
-        STAMP(5);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) pf[e][1] = pack_step(st[e], 1);
-        pv_slices(3, vg, 24, 8);
         uint4 n3[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            pf[e][2] = pack_step(st[e], 2);
             n3[e] = pack_step(st[e], 3);
+            l_before[e] = l[e];
+            const float tile_sum = (ts[e][1] + st[e][31]) + ts[e][0];
+            l[e] += tile_sum;
+            within = within && (tile_sum < kTileSumLimit);  // false for NaN and infinity as well
         }
         __builtin_amdgcn_sched_barrier(0);
         pf[0][3] = n3[0];
@@ -371,18 +371,25 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
         ++iters_;
 #endif
         ++t;
-        go = (t + 1 < full_nkt) & (__all((alpha_pend[0] == 1.0f) & (alpha_pend[1] == 1.0f)) != 0);
+        within = __all(within) != 0;
+        go = (t + 1 < full_nkt) & within;
     }
-    if (__all((alpha_pend[0] == 1.0f) & (alpha_pend[1] == 1.0f))) break;
+    if (within) break;
+    // P^T in registers belongs to tile t (now the ring's current slot) and is not to be trusted: redo that tile
     drain_matrix_pipe(o);
+    {
+        f32x16_t s[2][2];
+        qk_tile(cur, s);
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < 2; ++e) {
+            l[e] = l_before[e];
+            softmax_tile(e, s[e][0], s[e][1], t * kBN, false);
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+            for (int d = 0; d < 4; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[e][d][r] *= alpha_pend[e];
-        l[e] *= alpha_pend[e];
-        alpha_pend[e] = 1.0f;
+                for (int r = 0; r < 16; ++r) o[e][d][r] *= alpha_pend[e];
+            alpha_pend[e] = 1.0f;
+        }
     }
     }
 #ifdef EXT_STAMPS
@@ -401,7 +408,6 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 rescale_o(e);
-                l[e] = l[e] * alpha_pend[e] + sum_tile(e);
                 alpha_pend[e] = 1.0f;
             }
             f32x16_t s[2][2];
