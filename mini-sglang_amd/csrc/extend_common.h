@@ -17,6 +17,7 @@ constexpr int kBN = 64;           // keys per LDS tile
 constexpr int kHD = 128;          // head dim
 constexpr int kKRow = 256;        // bytes per K row in LDS (swizzled 16-byte chunks)
 constexpr int kVRow = 320;        // bytes per V row in LDS (padded: conflict-free transposed reads)
+constexpr int kKRowPadded = 272;  // K rows of the four-wave kernel: 16 bytes of padding instead of a swizzle
 constexpr int kKBytes = kBN * kKRow;
 constexpr int kTileBytes = kBN * kKRow + kBN * kVRow;
 
@@ -133,23 +134,31 @@ __device__ __forceinline__ StageRegs<KPT> stage_load(const uint16_t* kcol, const
     return r;
 }
 
-template <int KPT, int KSTEP>
+// The K image of a tile comes in two forms: rows of kKRow bytes with the 16-byte chunks XOR-swizzled by the row
+// (KROW == kKRow), or rows padded to kKRowPadded bytes with the chunks in place (both conflict-free for the fragment
+// reads; with padded rows the eight k-steps of a lane's fragments are one base address plus immediates).
+template <int KROW>
+__device__ __forceinline__ int k_chunk_offset(int key, int c16) {
+    return key * KROW + ((KROW == kKRow ? (c16 ^ (key & 15)) : c16) << 4);
+}
+
+template <int KPT, int KSTEP, int KROW = kKRow>
 __device__ __forceinline__ void stage_write(char* tile, int skey, int c16, const StageRegs<KPT>& r) {
     // keys skey + i * KSTEP: KSTEP is a multiple of 16, so (key & 15) == (skey & 15) for every i
-    char* kd = tile + skey * kKRow + ((c16 ^ (skey & 15)) << 4);
-    char* vd = tile + kKBytes + skey * kVRow + (c16 << 4);
+    char* kd = tile + k_chunk_offset<KROW>(skey, c16);
+    char* vd = tile + kBN * KROW + skey * kVRow + (c16 << 4);
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-        *reinterpret_cast<u32x4_t*>(kd + i * KSTEP * kKRow) = r.k[i];
+        *reinterpret_cast<u32x4_t*>(kd + i * KSTEP * KROW) = r.k[i];
         *reinterpret_cast<u32x4_t*>(vd + i * KSTEP * kVRow) = r.v[i];
     }
 }
 
 // one key of a thread's share at a time, for callers that spread the staging over their matrix work
-template <int KSTEP, int KPT>
+template <int KSTEP, int KROW = kKRow, int KPT>
 __device__ __forceinline__ void stage_write_one(char* tile, int skey, int c16, const StageRegs<KPT>& r, int i) {
-    *reinterpret_cast<u32x4_t*>(tile + skey * kKRow + ((c16 ^ (skey & 15)) << 4) + i * KSTEP * kKRow) = r.k[i];
-    *reinterpret_cast<u32x4_t*>(tile + kKBytes + skey * kVRow + (c16 << 4) + i * KSTEP * kVRow) = r.v[i];
+    *reinterpret_cast<u32x4_t*>(tile + k_chunk_offset<KROW>(skey, c16) + i * KSTEP * KROW) = r.k[i];
+    *reinterpret_cast<u32x4_t*>(tile + kBN * KROW + skey * kVRow + (c16 << 4) + i * KSTEP * kVRow) = r.v[i];
 }
 template <int KPT>
 __device__ __forceinline__ void stage_load_one(const uint16_t* kcol, const uint16_t* vcol, uint32_t cache_stride, const StageSlots<KPT>& sl,
@@ -161,8 +170,9 @@ __device__ __forceinline__ void stage_load_one(const uint16_t* kcol, const uint1
 
 // Diagnostic build only (-DEXT_STAMPS, see tools/extend_bench.hip): cycle stamps around the segments of the steady-state
 // loop, summed over two waves of every work group.  Each stamp drains the LDS queue, so the segment times are upper
-// bounds; no stamp exists in the library build.
-#ifdef EXT_STAMPS
+// bounds; no stamp exists in the library build.  -DEXT_STAMPS=2 stamps the loop as a whole only (cycles and the 100 MHz
+// real-time counter: cycles per iteration undisturbed, and the clock the chip holds in the loop).
+#if defined(EXT_STAMPS) && EXT_STAMPS != 2
 #define STAMP(i)                                                             \
     do {                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                   \

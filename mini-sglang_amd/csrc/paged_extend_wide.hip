@@ -9,6 +9,9 @@
 //   - no second wave on the SIMD that runs the same segment at the same time and competes for the matrix pipe and
 //     the vector issue port in lockstep; the two heads of a wave are interleaved by program order instead.
 // The two heads of a wave see the same rows, hence the same causal structure: one set of loop bounds.
+#include <type_traits>
+#include <utility>
+
 #include "extend_common.h"
 
 namespace msgl {
@@ -41,18 +44,60 @@ __device__ __forceinline__ void drain_matrix_pipe(f32x16_t (&o)[2][4]) {
 }
 
 // One v_add_f32 the compiler cannot pair with its neighbour into a v_pk_add_f32: beside matrix instructions the packed
-// form costs more issue time than the two plain adds it replaces.
+// form costs more issue time than the two plain adds it replaces.  The compiler cannot see into the statement, so it is
+// the caller's business that b is not the result of the instruction right before it when that is a transcendental
+// (v_exp_f32): their consumer needs one wait state, and without it half the lanes read a stale value.
 __device__ __forceinline__ float add_alone(float a, float b) {
     float r;
     asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 
+// Diagnostic builds only (-DEXT_KO=mask, scripts/ab_extend.sh): parts of the steady-state loop left out to see what each
+// costs; the results of such a build are wrong.  1 exponent fma, 2 exponential, 4 lane sums, 8 packs, 16 ring writes,
+// 32 ring loads, 64 K fragment reads, 128 V^T fragment reads.
+#ifndef EXT_KO
+#define EXT_KO 0
+#endif
+constexpr int kKo = EXT_KO;
+
+// f(integral_constant<int, Lo>), ..., f(integral_constant<int, Hi - 1>): a loop whose index is a constant expression in
+// the body, so that register arrays are indexed by constants before any optimisation runs
+template <int Lo, int... I, typename F>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, Lo + I>{}), ...);
+}
+template <int Lo, int Hi, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl<Lo>(f, std::make_integer_sequence<int, Hi - Lo>{});
+}
+
+// Schedule of the steady-state loop's softmax over the 64 slices (one matrix instruction each) of an iteration.  Item k
+// is element k / 2 of head k & 1 of the next tile's scores.  The first 32 keys' scores exist when the iteration starts,
+// the other 32 are complete after slice 31: their 32 items go into slices 34..63, two slices taking two.
+__host__ __device__ __forceinline__ constexpr int exp_slice(int k) {
+    if (k < 32) return k + 1;
+    const int j = k - 32;
+    return 34 + j - (j >= 11 ? 1 : 0) - (j >= 22 ? 1 : 0);
+}
+// Pair pr (elements 8s + 2pr, + 1) of head e goes into P^T of k-step s two slices after its second exponential, and not
+// before the fourth slice after the last matrix instruction that reads the old P^T of that k-step and head (k-steps 0,
+// 1: slices 0..15; 2, 3: slices 32..47; head e on the odd or even ones).  The distance matters: a matrix instruction
+// reads its B operand while it executes, not when it is issued - a pack one slice behind the last reader corrupted the
+// columns of four of its eight passes.  A result past 63 means: after the last slice.
+__host__ __device__ __forceinline__ constexpr int pack_slice(int e, int s, int pr) {
+    const int ready = exp_slice(16 * s + 4 * pr + 2 + e) + 2;
+    const int last_reader = (s < 2 ? 8 * s : 32 + 8 * (s - 2)) + 6 + e;
+    return ready > last_reader + 4 ? ready : last_reader + 4;
+}
+
 __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams p) {
     constexpr int KPT = 4;     // keys staged per thread and tile
     constexpr int KSTEP = 16;  // distance between a thread's staged keys
-    constexpr int ST = 3;
-    extern __shared__ __attribute__((aligned(256))) char lds[];  // ST * kTileBytes
+    // a ring slot: 64 K rows padded to kKRowPadded bytes (the chunks of a row in place: a lane's K fragments of the eight
+    // k-steps are one address plus immediates), then 64 V rows of kVRow bytes
+    constexpr int KROW = kKRowPadded, kKImage = kBN * KROW, kSlot = kKImage + kBN * kVRow;
+    extern __shared__ __attribute__((aligned(256))) char lds[];  // 4 * kSlot
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,8 +174,8 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
         for (int s = 0; s < 4; ++s) pf[e][s] = make_uint4(0, 0, 0, 0);
 
     const int g1 = (lane >> 4) & 1, iq = (lane & 15) >> 2, ip = lane & 3;
-    const int k_lane = n * kKRow + ((h ^ (n & 15)) << 4);
-    const int v_lane = kKBytes + (4 * h + iq) * kVRow + (16 * g1 + 4 * ip) * 2;
+    const int k_lane = n * KROW + (h << 4);
+    const int v_lane = kKImage + (4 * h + iq) * kVRow + (16 * g1 + 4 * ip) * 2;
 
     auto v_pair = [&](int tile, int s, int d0, short8_t (&vf)[4]) {  // V^T fragments of k-step s, output blocks d0 and d0 + 1
         const char* vp = lds + tile + v_lane + 16 * s * kVRow;
@@ -160,9 +205,9 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
             for (int r = 0; r < 16; ++r) s[e][0][r] = 0.f, s[e][1][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const char* ka = lds + (kp ^ (uint32_t)(ks << 5));
+            const char* ka = lds + kp + (ks << 5);
             const uint4 a0 = *reinterpret_cast<const uint4*>(ka);
-            const uint4 a1 = *reinterpret_cast<const uint4*>(ka + 32 * kKRow);
+            const uint4 a1 = *reinterpret_cast<const uint4*>(ka + 32 * KROW);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 s[e][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(qf[e][ks]), s[e][0], 0, 0, 0);
@@ -231,15 +276,23 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
     const int skey = tid >> 4;
     const uint16_t* kcol = p.kc + hk * kHD + c16 * 8;
     const uint16_t* vcol = p.vc + hk * kHD + c16 * 8;
+    // The ring has four slots: in the steady state an iteration reads three tiles (V of tile t, the second half of K of
+    // tile t+1, the first half of K of tile t+2) while tile t+3 is written, and a tile is first read two barriers after
+    // its writes were issued.  s0 = slot of tile t, s1 = t+1, s2 = t+2, s3 = the one being written.
+    int s0 = 0, s1 = kSlot, s2 = 2 * kSlot, s3 = 3 * kSlot;
+    auto advance_ring = [&]() {
+        const int c = s0;
+        s0 = s1, s1 = s2, s2 = s3, s3 = c;
+    };
     StageSlots<KPT> slots = stage_slots<KPT, KSTEP>(r2t_row, 0, skey, kv_len);
     StageRegs<KPT> stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
-    slots = stage_slots<KPT, KSTEP>(r2t_row, min(1, nkt - 1), skey, kv_len);
-    stage_write<KPT, KSTEP>(lds, skey, c16, stg);
-    stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
-    slots = stage_slots<KPT, KSTEP>(r2t_row, min(2, nkt - 1), skey, kv_len);
-    stage_write<KPT, KSTEP>(lds + kTileBytes, skey, c16, stg);
-    stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
-    slots = stage_slots<KPT, KSTEP>(r2t_row, min(3, nkt - 1), skey, kv_len);
+#pragma unroll
+    for (int k = 1; k <= 3; ++k) {
+        slots = stage_slots<KPT, KSTEP>(r2t_row, min(k, nkt - 1), skey, kv_len);
+        stage_write<KPT, KSTEP, KROW>(lds + (k - 1) * kSlot, skey, c16, stg);
+        stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
+    }
+    slots = stage_slots<KPT, KSTEP>(r2t_row, min(4, nkt - 1), skey, kv_len);
     __syncthreads();
     if (my_nkt > 0) {
         f32x16_t s[2][2];
@@ -251,23 +304,46 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
         }
     }
 
-    int cur = 0, nxt = kTileBytes, nn = 2 * kTileBytes;
-    auto advance_ring = [&]() {
-        const int c = cur;
-        cur = nxt, nxt = nn, nn = c;
-    };
     int t = 0;
-    // ---- steady state: tile t+1 is visible to every row of the wave ----
+    // ---- steady state: tiles t+1 and (where the loop goes on) t+2 are visible to every row of the wave ----
+    // Every 64-key tile is two halves of 32 keys with an S^T accumulator pair (one per head) each, and the iteration is
+    // four blocks of 16 matrix instructions:
+    //   1. O^T += V^T P^T of tile t, k-steps 0 and 1     beside  the exponentials of tile t+1, first half (scores kept
+    //   2. S^T of tile t+1, second half of its keys              from block 4 of the iteration before)
+    //   3. O^T of tile t, k-steps 2 and 3                beside  the exponentials of tile t+1, second half
+    //   4. S^T of tile t+2, first half of its keys
+    // so the softmax arithmetic is dealt over all 64 matrix instructions of the iteration, one exponential per matrix
+    // instruction, each matrix instruction a fenced slice of its own.  P^T of a k-step is packed into the registers of
+    // the old one once that k-step's matrix instructions have been issued.
+    //
     // The loop never looks at the maximum of a tile's scores.  Probabilities are taken relative to the reference maximum
     // m of the row as it stands (the exact maximum of the last tile that went through softmax_tile); what the loop
-    // watches is each lane's sum of the tile's probabilities.
-    // While that stays under kTileSumLimit nothing can overflow and nothing loses precision, whatever the scores did.
-    // The iteration that crosses the bound is the loop's last: its probabilities are discarded, the tile is redone with
-    // its exact maximum outside (O^T and the row sums rescaled), and the loop is entered again.
+    // watches is each lane's sum of the tile's probabilities.  While that stays under kTileSumLimit nothing can overflow
+    // and nothing loses precision, whatever the scores did.  The iteration that crosses the bound is the loop's last: its
+    // probabilities are discarded, the tile is redone with its exact maximum outside (O^T and the row sums rescaled),
+    // and the loop is entered again.
+    f32x16_t sa[2], sb[2];  // S^T of a tile's first / second 32 keys, one accumulator per head
+    short8_t vf[4];         // V^T fragments of k-step 0 of the tile whose O^T comes next
+    auto k_frag = [&](uint32_t base, int ks) { return *reinterpret_cast<const uint4*>(lds + base + (ks << 5)); };
+    if (1 < full_nkt) {
+        const uint32_t kp = s1 + k_lane;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sa[e][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const uint4 a = k_frag(kp, ks);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) sa[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(qf[e][ks]), sa[e], 0, 0, 0);
+        }
+        v_step(s0, 0, vf);
+    }
 #ifdef EXT_STAMPS
     unsigned long long acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
     int iters_ = 0;
+    const unsigned long long loop_c0_ = last_, loop_r0_ = __builtin_amdgcn_s_memrealtime();
 #endif
     for (;;) {
     // (one basic block: a second exit inside the body would let the compiler sink the softmax arithmetic, whose results
@@ -276,110 +352,127 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
     bool within = true;
     while (go) {
         STAMP(0);
-        __syncthreads();
+        // LDS operations of a wave complete in order, and the K fragments read in block 4 were waited for: every ring
+        // write of the iteration before (all issued before those reads) has landed
+        asm volatile("s_barrier" ::: "memory");
         STAMP(1);
-        // S^T of tile t+1 for both heads in eight fenced slices (one per k-step: the K fragments of k-step ks + 2 are
-        // requested before the four matrix instructions of k-step ks), with the ring-slot writes of tile t+2, the loads
-        // of tile t+3 and the first V^T fragments of tile t in the slices.
-        f32x16_t s[2][2];
-        short8_t vf[4], vg[4];
-        uint4 ka[3][2];
-        const uint32_t kp = nxt + k_lane;
-        auto k_read = [&](int ks) {
-            const char* a = lds + (kp ^ (uint32_t)(ks << 5));
-            ka[ks % 3][0] = *reinterpret_cast<const uint4*>(a);
-            ka[ks % 3][1] = *reinterpret_cast<const uint4*>(a + 32 * kKRow);
-        };
-        k_read(0);
-        k_read(1);
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[e][0][r] = 0.f, s[e][1][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            if (ks + 2 < 8) k_read(ks + 2);
-            if (ks < KPT) stage_write_one<KSTEP>(lds + nn, skey, c16, stg, ks);
-            else stage_load_one(kcol, vcol, p.cache_stride, slots, stg, ks - KPT);
-            if (ks == 7) slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + ST + 1, nkt - 1), skey, kv_len);
-            if (ks >= 6) v_pair(cur, 0, 2 * (ks - 6), vf);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                s[e][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ka[ks % 3][0]), as_bf16x8(qf[e][ks]), s[e][0], 0, 0, 0);
-                s[e][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ka[ks % 3][1]), as_bf16x8(qf[e][ks]), s[e][1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#ifdef EXT_STAMPS
-            if (ks == 0) STAMP(7);
-            if (ks == 3) STAMP(8);
-#endif
-        }
-        STAMP(2);
-        float st[2][32];
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[e][r] = s[e][0][r], st[e][16 + r] = s[e][1][r];
-        // O^T of tile t: 32 matrix instructions (k-step, output block, head), one fenced slice each, with the softmax of
-        // tile t+1 dealt over the slices: slice g exponentiates element g of either head, adds element g-1 to the lane's
-        // tile sums (two chains per head), and from k-step 1 on packs one pair of the previous k-step's elements into
-        // P^T, whose old value that k-step's matrix instructions have consumed by then.
-        v_step(cur, 1, vg);
+        short8_t vg[4];
+        uint4 ka[3];
         float ts[2][2];
+        if (kKo) {  // whatever a diagnostic build leaves out still has a defined (and opaque) value
 #pragma unroll
-        for (int g = 0; g < 32; ++g) {
-            const int ks = g >> 3, i = g & 7, d = i >> 1, e = i & 1;
-            if (g == 8) v_step(cur, 2, vf);
-            if (g == 16) v_step(cur, 3, vg);
-            mfma_into_agpr(o[e][d], __builtin_bit_cast(u32x4_t, (ks & 1) ? vg[d] : vf[d]), __builtin_bit_cast(u32x4_t, pf[e][ks]));
+            for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(vg[i]));
 #pragma unroll
-            for (int he = 0; he < 2; ++he) {
-                st[he][g] = fast_exp2(__builtin_fmaf(st[he][g], p.scale_log2e, -m[he]));
-                if (g == 1 || g == 2) ts[he][(g - 1) & 1] = st[he][g - 1];
-                else if (g > 2) ts[he][(g - 1) & 1] = add_alone(ts[he][(g - 1) & 1], st[he][g - 1]);
-            }
-            if (ks >= 1) {
-                const int he = i >> 2, pr = i & 3, r = 8 * (ks - 1) + 2 * pr;
-                const uint32_t w = pack_bf16(st[he][r], st[he][r + 1]);
-                if (pr == 0) pf[he][ks - 1].x = w;
-                else if (pr == 1) pf[he][ks - 1].y = w;
-                else if (pr == 2) pf[he][ks - 1].z = w;
-                else pf[he][ks - 1].w = w;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#ifdef EXT_STAMPS
-            if (g == 7) STAMP(3);
-            if (g == 15) STAMP(4);
-            if (g == 23) STAMP(5);
-#endif
+            for (int i = 0; i < 3; ++i) asm volatile("" : "=v"(ka[i]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(ts[i >> 1][i & 1]));
         }
-        uint4 n3[2];
+        const uint32_t kp1 = s1 + k_lane + 32 * KROW, kp2 = s2 + k_lane;
+        auto slice = [&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value, blk = g >> 4, j = g & 15;
+            // ---- LDS reads: V^T fragments a k-step or more ahead of their use, K fragments two k-steps ahead
+            if constexpr (g == 0 && !(kKo & 128)) v_pair(s0, 1, 0, vg);
+            if constexpr (g == 1 && !(kKo & 128)) v_pair(s0, 1, 2, vg);
+            if constexpr (g == 8 && !(kKo & 128)) v_pair(s0, 2, 0, vf);
+            if constexpr (g == 9 && !(kKo & 128)) v_pair(s0, 2, 2, vf);
+            if constexpr (g == 16 && !(kKo & 128)) v_pair(s0, 3, 0, vg);
+            if constexpr (g == 17 && !(kKo & 128)) v_pair(s0, 3, 2, vg);
+            if constexpr (g == 56 && !(kKo & 128)) v_pair(s1, 0, 0, vf);
+            if constexpr (g == 58 && !(kKo & 128)) v_pair(s1, 0, 2, vf);
+            if constexpr (g >= 12 && g <= 26 && (g & 1) == 0 && !(kKo & 64)) ka[((g - 12) >> 1) % 3] = k_frag(kp1, (g - 12) >> 1);
+            if constexpr (g >= 44 && g <= 58 && (g & 1) == 0 && !(kKo & 64)) ka[((g - 44) >> 1) % 3] = k_frag(kp2, (g - 44) >> 1);
+            // ---- ring: tile t+3 into the free slot, tile t+4 into the registers that frees, then the slots of tile t+5
+            if constexpr (g < 32 && (g & 7) == 1 && !(kKo & 16)) stage_write_one<KSTEP, KROW>(lds + s3, skey, c16, stg, g >> 3);
+            if constexpr (g < 32 && (g & 7) == 5 && !(kKo & 32)) stage_load_one(kcol, vcol, p.cache_stride, slots, stg, g >> 3);
+            if constexpr (g == 33) slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + 5, nkt - 1), skey, kv_len);
+            // ---- the slice's matrix instruction
+            if constexpr (blk == 0 || blk == 2) {
+                constexpr int ks = (blk ? 2 : 0) + (j >> 3), d = (j & 7) >> 1, e = j & 1;
+                mfma_into_agpr(o[e][d], __builtin_bit_cast(u32x4_t, (ks & 1) ? vg[d] : vf[d]), __builtin_bit_cast(u32x4_t, pf[e][ks]));
+            } else {
+                constexpr int ks = j >> 1, e = j & 1;
+                f32x16_t& acc = blk == 1 ? sb[e] : sa[e];
+                f32x16_t zero;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ka[ks % 3]), as_bf16x8(qf[e][ks]), ks == 0 ? zero : acc, 0, 0, 0);
+            }
+            // ---- softmax of tile t+1, item k = element k / 2 of head k & 1: exponent formed in the slice before its
+            // exponential (so that the two do not wait on each other), added to its lane sum (two chains per head) two
+            // slices after it (a matrix instruction between the v_exp_f32 and the add: see add_alone), packed into P^T
+            // two slices after its pair is complete
+            static_for<0, 6>([&](auto dkc) __attribute__((always_inline)) {
+                constexpr int k = g + decltype(dkc)::value - 4;
+                if constexpr (k >= 0 && k < 64) {
+                    constexpr int he = k & 1, el = k >> 1, c = el & 1;
+                    if constexpr (exp_slice(k) - 1 == g && !(kKo & 1)) {
+                        if constexpr (el < 16) sa[he][el] = __builtin_fmaf(sa[he][el], p.scale_log2e, -m[he]);
+                        else sb[he][el - 16] = __builtin_fmaf(sb[he][el - 16], p.scale_log2e, -m[he]);
+                    }
+                    if constexpr (exp_slice(k) == g && !(kKo & 2)) {
+                        if constexpr (el < 16) sa[he][el] = fast_exp2(sa[he][el]);
+                        else sb[he][el - 16] = fast_exp2(sb[he][el - 16]);
+                    }
+                    if constexpr (exp_slice(k) + 2 == g && !(kKo & 4)) {
+                        float x;
+                        if constexpr (el < 16) x = sa[he][el];
+                        else x = sb[he][el - 16];
+                        if constexpr (el < 2) ts[he][c] = x;
+                        else ts[he][c] = add_alone(ts[he][c], x);
+                    }
+                }
+            });
+            static_for<0, 32>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = decltype(qc)::value, he = q & 1, pr = (q >> 1) & 3, s = q >> 3, el = 8 * s + 2 * pr;
+                if constexpr (pack_slice(he, s, pr) == g && !(kKo & 8)) {
+                    float x0, x1;
+                    if constexpr (el < 16) x0 = sa[he][el], x1 = sa[he][el + 1];
+                    else x0 = sb[he][el - 16], x1 = sb[he][el + 1 - 16];
+                    const uint32_t w = pack_bf16(x0, x1);
+                    if constexpr (pr == 0) pf[he][s].x = w;
+                    else if constexpr (pr == 1) pf[he][s].y = w;
+                    else if constexpr (pr == 2) pf[he][s].z = w;
+                    else pf[he][s].w = w;
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        static_for<0, 16>(slice);
+        STAMP(2);
+        static_for<16, 32>(slice);
+        STAMP(3);
+        static_for<32, 48>(slice);
+        STAMP(4);
+        static_for<48, 64>(slice);
+        STAMP(5);
+        // what did not fit: the adds of the last element of either head (plain adds: the compiler sees what precedes them)
+        // and the last pair of either head (elements 30, 31) of k-step 3
+        static_assert(exp_slice(63) == 63 && exp_slice(62) == 62 && exp_slice(61) == 61 && pack_slice(0, 3, 3) > 63 && pack_slice(0, 3, 2) <= 63,
+                      "schedule");
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            n3[e] = pack_step(st[e], 3);
+            ts[e][1] += sb[e][15];
+            pf[e][3].w = pack_bf16(sb[e][14], sb[e][15]);
             l_before[e] = l[e];
-            const float tile_sum = (ts[e][1] + st[e][31]) + ts[e][0];
+            const float tile_sum = ts[e][0] + ts[e][1];
             l[e] += tile_sum;
             within = within && (tile_sum < kTileSumLimit);  // false for NaN and infinity as well
         }
-        __builtin_amdgcn_sched_barrier(0);
-        pf[0][3] = n3[0];
-        pf[1][3] = n3[1];
         advance_ring();
         STAMP(6);
 #ifdef EXT_STAMPS
         ++iters_;
 #endif
         ++t;
-        within = __all(within) != 0;
+        within = kKo ? true : __all(within) != 0;
         go = (t + 1 < full_nkt) & within;
     }
     if (within) break;
-    // P^T in registers belongs to tile t (now the ring's current slot) and is not to be trusted: redo that tile
+    // P^T in registers belongs to tile t (now the ring's first slot) and is not to be trusted: redo that tile
     drain_matrix_pipe(o);
     {
         f32x16_t s[2][2];
-        qk_tile(cur, s);
+        qk_tile(s0, s);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             l[e] = l_before[e];
@@ -396,14 +489,18 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
     if (lane == 0 && wave == 0) {
         for (int i = 0; i < 10; ++i) atomicAdd(&g_stamps_wide[i], acc_[i]);
         atomicAdd(&g_stamps_wide[15], (unsigned long long)iters_);
+        if (iters_ > 0) {  // the loop as a whole (with the rare exits to redo a tile)
+            atomicAdd(&g_stamps_wide[10], (unsigned long long)__builtin_amdgcn_s_memtime() - loop_c0_);
+            atomicAdd(&g_stamps_wide[11], (unsigned long long)__builtin_amdgcn_s_memrealtime() - loop_r0_);
+        }
     }
 #endif
     // ---- the diagonal tiles, then the tiles only other waves of the work group still need ----
     for (; t < nkt; ++t) {
         __syncthreads();
-        stage_write<KPT, KSTEP>(lds + nn, skey, c16, stg);
+        stage_write<KPT, KSTEP, KROW>(lds + s3, skey, c16, stg);
         stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);  // past the last tile: a copy of it into a free slot
-        slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + ST + 1, nkt - 1), skey, kv_len);
+        slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + 5, nkt - 1), skey, kv_len);
         if (t < my_nkt) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -412,12 +509,12 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
             }
             f32x16_t s[2][2];
             const bool more = t + 1 < my_nkt;
-            if (more) qk_tile(nxt, s);
-            short8_t vf[4];
+            if (more) qk_tile(s1, s);
+            short8_t vt[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                v_step(cur, ks, vf);
-                pv_step(ks, vf);
+                v_step(s0, ks, vt);
+                pv_step(ks, vt);
             }
             if (more) {
 #pragma unroll
@@ -459,7 +556,7 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
 }
 
 int launch_extend_wide(const ExtendParams& p, int64_t blocks, hipStream_t stream) {
-    constexpr int kLds = 3 * kTileBytes;
+    constexpr int kLds = 4 * (kBN * kKRowPadded + kBN * kVRow);
     static PerDeviceOnce once;
     if (!once.ensure([] {
             return hipFuncSetAttribute(reinterpret_cast<const void*>(paged_extend_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -10,23 +10,26 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unus
 if [ "$1" = build ]; then
     shift
     mkdir -p tools/ko
-    rm -f tools/ko/ab_*
+    rm -f tools/ko/ab_* tools/ko/lib_*
     make -C $C >/dev/null
-    /opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 -c tools/extend_bench.hip -o /tmp/eb_ab.o
-    OBJS=$(ls $C/*.o | grep -v "paged_extend_wide.o")
+    # (every variant carries the two whole-loop stamps of -DEXT_STAMPS=2: cycles per steady-state iteration and the clock)
+    /opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 -DEXT_STAMPS -c tools/extend_bench.hip -o /tmp/eb_ab.o
+    /opt/rocm/bin/hipcc $FLAGS -DEXT_STAMPS=2 -c $C/paged_extend.hip -o /tmp/pe_ab.o
+    OBJS="/tmp/pe_ab.o $(ls $C/*.o | grep -v "paged_extend_wide.o\|paged_extend.o")"
     for nv in "$@"; do
         name=${nv%%=*}; src=${nv#*=}; extra=""
         case "$src" in *:*) extra=${src#*:}; src=${src%%:*};; esac
         cp "$src" $C/_ab_variant.hip
-        /opt/rocm/bin/hipcc $FLAGS $extra -c $C/_ab_variant.hip -o /tmp/ab_$name.o
+        /opt/rocm/bin/hipcc $FLAGS -DEXT_STAMPS=2 $extra -c $C/_ab_variant.hip -o /tmp/ab_$name.o
         rm -f $C/_ab_variant.hip
         /opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/eb_ab.o /tmp/ab_$name.o $OBJS -o tools/ko/ab_$name
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/ab_$name.o $OBJS -o tools/ko/lib_$name.so  # for MSGL_HIP_LIB=
         echo "built tools/ko/ab_$name"
     done
 else
     rounds=${2:-3}
     for r in $(seq $rounds); do
-        for b in tools/ko/ab_*; do
+        for b in $(ls tools/ko/ab_*); do
             echo "== $(basename $b) round $r"
             timeout -k 10 120 $b --bs 1 --sq 16384 --steps 10 --warmup 3
             timeout -k 10 120 $b --bs 1 --sq 4096 --prefix 65536 --ps 64 --hq 8 --hkv 1 --steps 10 --warmup 3

@@ -14,8 +14,12 @@ if [ "$1" = build ]; then
     /opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 -DEXT_STAMPS -c tools/extend_bench.hip -o /tmp/eb_stamps.o
     OBJS=$(ls $C/*.o | grep -v "paged_extend.o\|paged_extend_wide.o")
     /opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/eb_stamps.o /tmp/pe_stamps.o /tmp/pew_stamps.o $OBJS -o tools/ko/extend_stamps
+    # the four-wave kernel with the loop stamped as a whole only: undisturbed cycles per iteration and the clock in the loop
+    /opt/rocm/bin/hipcc $FLAGS -DEXT_STAMPS=2 -c $C/paged_extend_wide.hip -o /tmp/pew_stamps2.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/eb_stamps.o /tmp/pe_stamps.o /tmp/pew_stamps2.o $OBJS -o tools/ko/extend_clock
 else
     timeout -k 10 120 tools/ko/extend_stamps --bs 2 --sq 16384 --steps 5 --warmup 2
+    timeout -k 10 120 tools/ko/extend_clock --bs 2 --sq 16384 --steps 40 --warmup 10
     MSGL_EXTEND_WIDE=0 timeout -k 10 120 tools/ko/extend_stamps --bs 2 --sq 16384 --steps 5 --warmup 2
     MSGL_EXTEND_NH=1 timeout -k 10 120 tools/ko/extend_stamps --bs 2 --sq 16384 --steps 5 --warmup 2
 fi

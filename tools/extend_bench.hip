@@ -142,12 +142,18 @@ int main(int argc, char** argv) {
         if (st_[15] == 0) msgl_extend_wide_stamps(st_);  // the launch took the one-wave-per-SIMD kernel
         const double it = (double)st_[15];
         printf("steady iterations sampled: %.0f; cycles per iteration by segment:\n", it);
-        const char* names[9] = {"loop edge", "barrier", "rescale+QK(t+1)+staging", "PV0+max", "PV1+exp12", "PV2+exp12", "PV3+exp8+pack",
-                                "(wide) QK slice 0", "(wide) QK slices 1-3"};
+        const bool wide_ = st_[7] == 0 && st_[8] == 0;  // the four-wave kernel stamps the edges of its four blocks
+        const char* names8[9] = {"loop edge", "barrier", "rescale+QK(t+1)+staging", "PV0+max", "PV1+exp12", "PV2+exp12", "PV3+exp8+pack",
+                                 "-", "-"};
+        const char* names4[9] = {"loop edge", "barrier", "PV k-steps 0,1", "QK second half", "PV k-steps 2,3", "QK first half", "tail of iteration",
+                                 "-", "-"};
+        const char** names = wide_ ? names4 : names8;
         double tot = 0;
         for (int i = 0; i < 9; ++i) tot += st_[i] / it;
         for (int i = 0; i < 9; ++i) printf("  %-22s %8.1f\n", names[i], st_[i] / it);
         printf("  %-22s %8.1f\n", "total", tot);
+        if (st_[11] > 0)
+            printf("  whole loop: %.1f cycles per iteration, clock %.3f GHz\n", st_[10] / it, (double)st_[10] / (double)st_[11] * 0.1);
     }
 #endif
     return 0;
