@@ -92,6 +92,10 @@ __host__ __device__ __forceinline__ constexpr int pack_slice(int e, int s, int p
 }
 
 __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams p) {
+#ifndef EXT_KD
+#define EXT_KD 2
+#endif
+    constexpr int KD = EXT_KD;  // K fragments are requested this many k-steps (of two slices) ahead of their use
     constexpr int KPT = 4;     // keys staged per thread and tile
     constexpr int KSTEP = 16;  // distance between a thread's staged keys
     // a ring slot: 64 K rows padded to kKRowPadded bytes (the chunks of a row in place: a lane's K fragments of the eight
@@ -357,13 +361,13 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
         asm volatile("s_barrier" ::: "memory");
         STAMP(1);
         short8_t vg[4];
-        uint4 ka[3];
+        uint4 ka[KD + 1];
         float ts[2][2];
         if (kKo) {  // whatever a diagnostic build leaves out still has a defined (and opaque) value
 #pragma unroll
             for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(vg[i]));
 #pragma unroll
-            for (int i = 0; i < 3; ++i) asm volatile("" : "=v"(ka[i]));
+            for (int i = 0; i < KD + 1; ++i) asm volatile("" : "=v"(ka[i]));
 #pragma unroll
             for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(ts[i >> 1][i & 1]));
         }
@@ -379,8 +383,10 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
             if constexpr (g == 17 && !(kKo & 128)) v_pair(s0, 3, 2, vg);
             if constexpr (g == 56 && !(kKo & 128)) v_pair(s1, 0, 0, vf);
             if constexpr (g == 58 && !(kKo & 128)) v_pair(s1, 0, 2, vf);
-            if constexpr (g >= 12 && g <= 26 && (g & 1) == 0 && !(kKo & 64)) ka[((g - 12) >> 1) % 3] = k_frag(kp1, (g - 12) >> 1);
-            if constexpr (g >= 44 && g <= 58 && (g & 1) == 0 && !(kKo & 64)) ka[((g - 44) >> 1) % 3] = k_frag(kp2, (g - 44) >> 1);
+            if constexpr (g >= 16 - 2 * KD && g <= 30 - 2 * KD && (g & 1) == 0 && !(kKo & 64))
+                ka[((g - (16 - 2 * KD)) >> 1) % (KD + 1)] = k_frag(kp1, (g - (16 - 2 * KD)) >> 1);
+            if constexpr (g >= 48 - 2 * KD && g <= 62 - 2 * KD && (g & 1) == 0 && !(kKo & 64))
+                ka[((g - (48 - 2 * KD)) >> 1) % (KD + 1)] = k_frag(kp2, (g - (48 - 2 * KD)) >> 1);
             // ---- ring: tile t+3 into the free slot, tile t+4 into the registers that frees, then the slots of tile t+5
             if constexpr (g < 32 && (g & 7) == 1 && !(kKo & 16)) stage_write_one<KSTEP, KROW>(lds + s3, skey, c16, stg, g >> 3);
             if constexpr (g < 32 && (g & 7) == 5 && !(kKo & 32)) stage_load_one(kcol, vcol, p.cache_stride, slots, stg, g >> 3);
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
                 f32x16_t zero;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ka[ks % 3]), as_bf16x8(qf[e][ks]), ks == 0 ? zero : acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ka[ks % (KD + 1)]), as_bf16x8(qf[e][ks]), ks == 0 ? zero : acc, 0, 0, 0);
             }
             // ---- softmax of tile t+1, item k = element k / 2 of head k & 1: exponent formed in the slice before its
             // exponential (so that the two do not wait on each other), added to its lane sum (two chains per head) two
