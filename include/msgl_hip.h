@@ -6,7 +6,8 @@
  * Conventions (all entry points):
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch-allocated
  *     tensors in the host mirror); the library never allocates or frees device
- *     memory and keeps no state besides a thread-local error string;
+ *     memory and keeps no state besides a thread-local error string (and the
+ *     test-only overrides of msgl_set_variant, which default to "library chooses");
  *   - activations / caches are bf16 (2-byte elements), index tensors int32,
  *     strides are in ELEMENTS of the tensor they describe;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
@@ -41,6 +42,32 @@ int msgl_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
 const char* msgl_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * Kernel-form overrides for tests and measurements (no counterpart in the reference).
+ * Several entry points choose between kernel forms that compute the same result
+ * (to rounding); by default the library chooses from the call's shape alone and
+ * reads nothing from its environment.  msgl_set_variant pins one choice process-wide
+ * until it is set back to MSGL_VARIANT_AUTO; a serving process never calls it.
+ * Returns the previous value, or MSGL_E_INVALID for an unknown `which`.
+ *   MSGL_VARIANT_DECODE_MFMA      0 = gather kernel only, 8 = matrix-core kernel only for 8 heads
+ *                                 per kv head, 4 = also for 4 heads per kv head on every shape
+ *   MSGL_VARIANT_DECODE_MFMA_WAVES  4 / 8 waves per (request, split) of the matrix-core decode kernel
+ *   MSGL_VARIANT_EXTEND_HEADS     1 / 2 query heads per extend work group
+ *   MSGL_VARIANT_EXTEND_WIDE      0 = eight waves (one head each), 1 = four waves (both heads each)
+ *   MSGL_VARIANT_EXTEND_RING      2 / 3 slots in the K/V tile ring of the eight-wave extend kernel
+ *   MSGL_VARIANT_EXTEND_KEY_SPLIT 1..8 key runs per extend work item (needs the workspace)
+ * ------------------------------------------------------------------------- */
+#define MSGL_VARIANT_AUTO (-1)
+#define MSGL_VARIANT_DECODE_MFMA 0
+#define MSGL_VARIANT_DECODE_MFMA_WAVES 1
+#define MSGL_VARIANT_EXTEND_HEADS 2
+#define MSGL_VARIANT_EXTEND_WIDE 3
+#define MSGL_VARIANT_EXTEND_RING 4
+#define MSGL_VARIANT_EXTEND_KEY_SPLIT 5
+#define MSGL_VARIANT_COUNT 6
+int msgl_set_variant(int which, int value);
+int msgl_get_variant(int which);
 
 /* ---------------------------------------------------------------------------
  * KV-pool store.

@@ -13,12 +13,14 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSGL_HIP_LIB", os.path.join(_HERE, "libmsgl_hip.so"))
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # name -> (restype, argtypes); mirrors include/msgl_hip.h and include/msgl_comm.h one to one
 SIGNATURES = {
     "msgl_abi_version": (c_int, []),
     "msgl_last_error": (c_char_p, []),
+    "msgl_set_variant": (c_int, [c_int, c_int]),
+    "msgl_get_variant": (c_int, [c_int]),
     "msgl_store_kv": (
         c_int,
         [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],

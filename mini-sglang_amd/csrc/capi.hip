@@ -34,7 +34,20 @@ int device_cus() {
     return cached[dev];
 }
 
+static int g_variant[MSGL_VARIANT_COUNT] = {MSGL_VARIANT_AUTO, MSGL_VARIANT_AUTO, MSGL_VARIANT_AUTO,
+                                            MSGL_VARIANT_AUTO, MSGL_VARIANT_AUTO, MSGL_VARIANT_AUTO};
+int variant(int which) { return __atomic_load_n(&g_variant[which], __ATOMIC_RELAXED); }
+
 }  // namespace msgl
 
-extern "C" int msgl_abi_version(void) { return 13; }
+extern "C" int msgl_set_variant(int which, int value) {
+    MSGL_REQUIRE(which >= 0 && which < MSGL_VARIANT_COUNT, "msgl_set_variant: unknown choice %d", which);
+    return __atomic_exchange_n(&msgl::g_variant[which], value < 0 ? MSGL_VARIANT_AUTO : value, __ATOMIC_RELAXED);
+}
+extern "C" int msgl_get_variant(int which) {
+    MSGL_REQUIRE(which >= 0 && which < MSGL_VARIANT_COUNT, "msgl_get_variant: unknown choice %d", which);
+    return msgl::variant(which);
+}
+
+extern "C" int msgl_abi_version(void) { return 14; }
 extern "C" const char* msgl_last_error(void) { return msgl::g_err; }

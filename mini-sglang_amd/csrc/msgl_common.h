@@ -30,6 +30,8 @@ struct PerDeviceOnce {
     }
 };
 int device_cus();
+// Current override of a kernel-form choice (msgl_set_variant), MSGL_VARIANT_AUTO = the library chooses.
+int variant(int which);
 
 #define MSGL_REQUIRE(cond, ...)            \
     do {                                   \

@@ -519,15 +519,15 @@ int launch_decode_mfma(const DecodeParams& p, int G, int Hkv, hipStream_t stream
 // is bound by its arithmetic there).  4 heads per kv head: ranks with 2 or 4 kv heads (TP 4 / 2 shards of a 32 q / 8 kv
 // model), where it measures 1-4 % ahead of the gather kernel at every batch size tried, and ranks with one kv head
 // (2-11 % ahead, most at small batches) unless the launch has a single split per request (256 requests x 8192 tokens,
-// one group each: the gather kernel is 3 % ahead); with 8 kv heads the two tie.  MSGL_DECODE_MFMA overrides for
-// measurements: "0" never, "8" G = 8 only, "4" G = 4 always, "4s" G = 4 only for ranks with one or two kv heads.
+// one group each: the gather kernel is 3 % ahead); with 8 kv heads the two tie.  Tests and measurements pin the choice
+// with msgl_set_variant(MSGL_VARIANT_DECODE_MFMA, 0 / 8 / 4).
 static bool use_mfma_decode(int G, int Hkv, int page_size, int max_splits) {
     if (page_size % kTile != 0 || (G != 8 && G != 4)) return false;
-    const char* e = getenv("MSGL_DECODE_MFMA");
-    if (e && e[0] == '0') return false;
+    const int forced = variant(MSGL_VARIANT_DECODE_MFMA);
+    if (forced == 0) return false;
     if (G == 8) return true;
-    if (e && e[0] == '8') return false;
-    if (e && e[0] == '4') return e[1] != 's' || Hkv <= 2;
+    if (forced == 8) return false;
+    if (forced == 4) return true;
     return Hkv == 2 || Hkv == 4 || (Hkv == 1 && max_splits > 1);
 }
 
@@ -697,6 +697,9 @@ extern "C" int msgl_paged_decode_static(const void* q, int64_t q_stride, const v
                                         int max_splits, int chunk_tokens, const int32_t* chunk_dev, int kv_stream,
                                         const int32_t* reuse_lens, const int32_t* plan, void* stream) {
     if (bs == 0) return MSGL_OK;
+    // (checked before the size below is formed: a negative count would wrap it)
+    MSGL_REQUIRE(bs > 0 && Hq > 0 && D == kD && max_splits >= 1 && max_splits <= 4096,
+                 "msgl_paged_decode_static: bs=%d Hq=%d D=%d max_splits=%d", bs, Hq, D, max_splits);
     const size_t need = max_splits > 1 ? msgl_paged_decode_workspace_bytes(bs, Hq, D, max_splits) : 0;
     if (need > (size_t)MSGL_PAGED_DECODE_STATIC_WORKSPACE_BYTES) {
         set_error("msgl_paged_decode_static: bs=%d x max_splits=%d x Hq=%d needs %zu bytes of split workspace, the built-in one holds "

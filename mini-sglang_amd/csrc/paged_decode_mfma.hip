@@ -311,12 +311,13 @@ int launch_decode_mfma(const DecodeParams& p, int G, int Hkv, hipStream_t stream
             // One or two kv heads per rank, launches of about one work group per CU (long contexts at small batch): 4 waves
             // per (request, split) instead of 8 -- half the LDS, so two groups fit a CU, and half the waves to merge at
             // the end.  Measured at 128k contexts: one kv head 7 % faster at batch 1, 6 % at 2, 1-3 % at 4-8, equal at 16;
-            // two kv heads 6 % at batch 1, 2 % at 4, 3 % SLOWER at 16.  MSGL_DECODE_MFMA_NW = 4 / 8 forces either.
+            // two kv heads 6 % at batch 1, 2 % at 4, 3 % SLOWER at 16.  msgl_set_variant(MSGL_VARIANT_DECODE_MFMA_WAVES, 4 / 8)
+            // forces either.
             case 1:
             case 2: {
-                const char* e = getenv("MSGL_DECODE_MFMA_NW");
+                const int forced = variant(MSGL_VARIANT_DECODE_MFMA_WAVES);
                 const int64_t grid = (int64_t)p.bs * p.max_splits, cus = device_cus();
-                const bool four = e ? atoi(e) == 4 : grid <= (Hkv == 1 ? 2 * cus : cus);
+                const bool four = forced > 0 ? forced == 4 : grid <= (Hkv == 1 ? 2 * cus : cus);
                 if (Hkv == 1) return four ? launch_mfma<8, 1, 4>(p, stream) : launch_mfma<8, 1>(p, stream);
                 return four ? launch_mfma<8, 2, 4>(p, stream) : launch_mfma<8, 2>(p, stream);
             }
@@ -326,8 +327,7 @@ int launch_decode_mfma(const DecodeParams& p, int G, int Hkv, hipStream_t stream
     } else if (G == 4) {
         switch (Hkv) {
             case 1: {  // 4 waves per group: 1-2 % ahead of 8 at every shape tried
-                const char* e = getenv("MSGL_DECODE_MFMA_NW");
-                return (e && atoi(e) == 8) ? launch_mfma<4, 1>(p, stream) : launch_mfma<4, 1, 4>(p, stream);
+                return variant(MSGL_VARIANT_DECODE_MFMA_WAVES) == 8 ? launch_mfma<4, 1>(p, stream) : launch_mfma<4, 1, 4>(p, stream);
             }
             case 2: return launch_mfma<4, 2>(p, stream);
             case 4: return launch_mfma<4, 4>(p, stream);

@@ -623,8 +623,8 @@ extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_
     p.ws_o = nullptr, p.ws_ml = nullptr;
     // query heads per work group: 2 share the staged K/V tile and give every SIMD two waves
     int nh = (p.group % 2 == 0) ? 2 : 1;
-    const char* nhe = getenv("MSGL_EXTEND_NH");
-    if (nhe) nh = (atoi(nhe) == 2 && p.group % 2 == 0) ? 2 : 1;
+    const int nh_forced = variant(MSGL_VARIANT_EXTEND_HEADS);  // tests / measurements only
+    if (nh_forced > 0) nh = (nh_forced == 2 && p.group % 2 == 0) ? 2 : 1;
     // Few work items with long key ranges (a short prompt on a long cached prefix, few heads per GPU): with a workspace
     // the key tiles of every item are cut into runs until the launch covers the chip; without one, one head per group
     // doubles the number of groups instead (one wave per SIMD: about a fifth slower per group).
@@ -638,7 +638,7 @@ extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_
         const int by_keys = (max_seqlen_k / kBN) / 8;  // at least eight key tiles per run
         ks = ks > kMaxKeySplit ? kMaxKeySplit : ks;
         ks = ks > by_keys ? by_keys : ks;
-        if (const char* e = getenv("MSGL_EXTEND_KSPLIT")) ks = atoi(e) < 1 ? 1 : (atoi(e) > kMaxKeySplit ? kMaxKeySplit : atoi(e));
+        if (const int f = variant(MSGL_VARIANT_EXTEND_KEY_SPLIT); f > 0) ks = f > kMaxKeySplit ? kMaxKeySplit : f;
         if ((size_t)ks * per_split > workspace_bytes) ks = (int)(workspace_bytes / per_split);
         if (ks > 1) {
             p.ksplit = ks;
@@ -646,13 +646,13 @@ extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_
             p.ws_ml = p.ws_o + (size_t)total_tokens * Hq * ks * D;
         }
     }
-    if (p.ksplit == 1 && !nhe && nh == 2 && items <= cus) nh = 1;
+    if (p.ksplit == 1 && nh_forced <= 0 && nh == 2 && items <= cus) nh = 1;
     const int64_t gx = (int64_t)bs * p.tiles_per_req * (Hq / nh) * p.ksplit;
     MSGL_REQUIRE(gx <= 0x7fffffff, "msgl_paged_extend: grid too large");
     // Requests of at most a dozen key tiles never reach the steady state the three-slot ring is built for; two
     // work groups per CU (two-slot ring, one head per group) overlap their start-up phases instead.
-    const char* se = getenv("MSGL_EXTEND_ST");
-    const bool two_slots = se ? atoi(se) == 2 : (max_seqlen_k > 0 && max_seqlen_k <= kShortKv);
+    const int ring_forced = variant(MSGL_VARIANT_EXTEND_RING);
+    const bool two_slots = ring_forced > 0 ? ring_forced == 2 : (max_seqlen_k > 0 && max_seqlen_k <= kShortKv);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (two_slots) {
         p.ksplit = 1;
@@ -663,8 +663,8 @@ extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_
     // Two heads per work group: 4 waves that own both heads each (one wave per SIMD, 512 registers) when the key ranges
     // are long enough for the steady state to dominate (measured +4..6 %); requests known to end within two dozen key
     // tiles spend most of their time on the diagonal, where 8 waves that own one head each are a few percent ahead.
-    const char* we = getenv("MSGL_EXTEND_WIDE");
-    const bool wide = nh == 2 && (we ? atoi(we) != 0 : !(max_seqlen_k > 0 && max_seqlen_k <= kWideMinKv));
+    const int wide_forced = variant(MSGL_VARIANT_EXTEND_WIDE);
+    const bool wide = nh == 2 && (wide_forced >= 0 ? wide_forced != 0 : !(max_seqlen_k > 0 && max_seqlen_k <= kWideMinKv));
     const int rc = wide ? launch_extend_wide(p, gx, st) : nh == 2 ? launch_extend<2, 3>(p, gx, st) : launch_extend<1, 3>(p, gx, st);
     if (rc || p.ksplit == 1) return rc;
     const int64_t rows = total_tokens * Hq;

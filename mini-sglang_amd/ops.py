@@ -16,6 +16,21 @@ _check = _capi.check
 
 DECODE_TILE = 16  # tokens per wave iteration of the decode kernel; split chunks are multiples of it
 
+# msgl_set_variant's choices (include/msgl_hip.h): tests and measurements pin a kernel form with them; the library
+# itself never reads its environment and a serving process leaves them all on "auto" (-1)
+VARIANTS = {"decode_mfma": 0, "decode_mfma_waves": 1, "extend_heads": 2, "extend_wide": 3, "extend_ring": 4, "extend_key_split": 5}
+
+
+def set_variant(name: str, value: Optional[int]) -> int:
+    """Pin (or, with None / -1, release) one kernel-form choice process-wide; returns the previous value."""
+    _need(name in VARIANTS, f"unknown variant {name!r} (one of {sorted(VARIANTS)})")
+    return int(_lib.msgl_set_variant(VARIANTS[name], -1 if value is None else int(value)))
+
+
+def reset_variants() -> None:
+    for which in VARIANTS.values():
+        _lib.msgl_set_variant(which, -1)
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream

@@ -32,7 +32,7 @@ def run(name, Hq, Hkv, ps, lens, layers=4, steps=8):
     outs = {}
     for rnd in range(2):
         for mode in ("0", "4"):
-            os.environ["MSGL_DECODE_MFMA"] = mode
+            ops.set_variant("decode_mfma", int(mode))
             for i in range(2):
                 f(i)
             torch.cuda.synchronize()

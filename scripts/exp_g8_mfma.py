@@ -1,13 +1,13 @@
-"""G = 8 decode: the matrix-core kernel against the vector gather kernel (MSGL_DECODE_G8=gather), one process each."""
+"""G = 8 decode: the matrix-core kernel against the vector gather kernel (msgl_set_variant), one process each."""
 import sys, os, subprocess, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) < 2:
     for mode in ("mfma", "gather"):
-        env = dict(os.environ, MSGL_DECODE_MFMA=("8" if mode == "mfma" else "0"))
-        subprocess.run([sys.executable, "-u", __file__, mode], env=env, check=False)
+        subprocess.run([sys.executable, "-u", __file__, mode], check=False)
     sys.exit(0)
 import torch
 from mini_sglang_amd import ops
+ops.set_variant("decode_mfma", 8 if sys.argv[1] == "mfma" else 0)
 from mini_sglang_amd.attn.hip_attn_backend import splits_for_batch
 from mini_sglang_amd.runtime import workload
 

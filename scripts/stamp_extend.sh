@@ -20,6 +20,6 @@ if [ "$1" = build ]; then
 else
     timeout -k 10 120 tools/ko/extend_stamps --bs 2 --sq 16384 --steps 5 --warmup 2
     timeout -k 10 120 tools/ko/extend_clock --bs 2 --sq 16384 --steps 40 --warmup 10
-    MSGL_EXTEND_WIDE=0 timeout -k 10 120 tools/ko/extend_stamps --bs 2 --sq 16384 --steps 5 --warmup 2
-    MSGL_EXTEND_NH=1 timeout -k 10 120 tools/ko/extend_stamps --bs 2 --sq 16384 --steps 5 --warmup 2
+    timeout -k 10 120 tools/ko/extend_stamps --bs 2 --sq 16384 --steps 5 --warmup 2 --wide 0
+    timeout -k 10 120 tools/ko/extend_stamps --bs 2 --sq 16384 --steps 5 --warmup 2 --heads 1
 fi

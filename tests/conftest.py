@@ -21,3 +21,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def variants():
+    """Pin kernel-form choices of the library (msgl_set_variant) for one test: variants("extend_wide", 0).  Every choice
+    is released again when the test ends."""
+    from mini_sglang_amd import ops
+
+    def pin(name, value):
+        ops.set_variant(name, None if value is None else int(value))
+
+    yield pin
+    ops.reset_variants()

@@ -265,7 +265,7 @@ def test_decode_planned_launch_is_bit_identical(Hq, Hkv, page_size):
 
 
 @pytest.mark.parametrize("Hq,Hkv,page_size", [(32, 8, 16), (4, 1, 64), (8, 2, 16), (16, 4, 32)])
-def test_decode_four_heads_per_kv_head_on_the_matrix_core_kernel(Hq, Hkv, page_size, monkeypatch):
+def test_decode_four_heads_per_kv_head_on_the_matrix_core_kernel(Hq, Hkv, page_size, variants):
     """The matrix-core decode kernel is built for 4 query heads per kv head as well (a measurement override; by default
     only 8 heads per kv head take it): same results as the gather kernel to fp32 / bf16 rounding, and within the bound
     of the oracle, over splits, a launch plan and the cache-policy hint."""
@@ -275,9 +275,9 @@ def test_decode_four_heads_per_kv_head_on_the_matrix_core_kernel(Hq, Hkv, page_s
     plan = ops.decode_plan(case["seq_lens"].to(DEV), 16, 272)
     reuse = torch.tensor([0, 0, 16, 16, 64, 512, 0, 1024, 4096], dtype=torch.int32, device=DEV)
     for kw in (dict(), dict(max_splits=16, chunk_tokens=272), dict(max_splits=16, chunk_tokens=272, plan=plan, reuse_lens=reuse)):
-        monkeypatch.setenv("MSGL_DECODE_MFMA", "0")
+        variants("decode_mfma", "0")
         gather = run_decode(case, page_size, **kw)
-        monkeypatch.setenv("MSGL_DECODE_MFMA", "4")
+        variants("decode_mfma", "4")
         mfma = run_decode(case, page_size, **kw)
         check_decode(case, mfma)
         assert (mfma.float() - gather.float()).abs().max().item() <= 8e-3
@@ -305,12 +305,12 @@ def test_decode_scores_that_grow_along_the_keys(Hq, Hkv):
 
 @pytest.mark.parametrize("waves", ["4", "8"])
 @pytest.mark.parametrize("Hq,Hkv", [(8, 1), (16, 2)])
-def test_decode_matrix_core_kernel_with_four_and_eight_waves(Hq, Hkv, waves, monkeypatch):
+def test_decode_matrix_core_kernel_with_four_and_eight_waves(Hq, Hkv, waves, variants):
     """The matrix-core decode kernel runs a (request, split) with 8 waves, or with 4 for one or two kv heads per rank on
     launches of about one work group per compute unit; the override forces either on the same cases (ragged lengths,
     splits, a launch plan, page sizes 16 and 64)."""
     ops = _ops()
-    monkeypatch.setenv("MSGL_DECODE_MFMA_NW", waves)
+    variants("decode_mfma_waves", waves)
     for ps, seq in ((16, [1, 15, 16, 17, 100, 1023, 1024, 2500, 4097]), (64, [5000, 64, 65, 8191])):
         case = build_case(Hq, Hkv, ps, seq, seed=211 + Hq + ps)
         plan = ops.decode_plan(case["seq_lens"].to(DEV), 16, 272)
@@ -386,19 +386,19 @@ def check_extend(case, out):
 EXTEND_FORMS = ["one-head", "two-heads-four-waves", "two-heads-eight-waves"]
 
 
-def _force_extend_form(monkeypatch, form):
+def _force_extend_form(variants, form):
     """The work-group shapes of the three-slot extend kernel: one query head per group (4 waves), two heads per group as
     4 waves that own both heads each (the default for an even number of heads per kv head), or as 8 waves that own one
-    head each.  The library reads the overrides per call."""
-    monkeypatch.setenv("MSGL_EXTEND_NH", "1" if form == "one-head" else "2")
-    monkeypatch.setenv("MSGL_EXTEND_WIDE", "0" if form == "two-heads-eight-waves" else "1")
+    head each.  Pinned through msgl_set_variant; the fixture releases every choice after the test."""
+    variants("extend_heads", "1" if form == "one-head" else "2")
+    variants("extend_wide", "0" if form == "two-heads-eight-waves" else "1")
 
 
 @pytest.mark.parametrize("form", EXTEND_FORMS)
 @pytest.mark.parametrize("Hq,Hkv", [(16, 8), (32, 8), (8, 1), (4, 4)])
 @pytest.mark.parametrize("page_size", [1, 16, 64])
-def test_extend(Hq, Hkv, page_size, form, monkeypatch):
-    _force_extend_form(monkeypatch, form)
+def test_extend(Hq, Hkv, page_size, form, variants):
+    _force_extend_form(variants, form)
     ps = page_size
     prefix = [0, 0, ps * 2, 0, 64 * ps // ps * (ps if ps > 1 else 1), 0]
     prefix = [p - p % ps for p in prefix]
@@ -408,19 +408,19 @@ def test_extend(Hq, Hkv, page_size, form, monkeypatch):
 
 
 @pytest.mark.parametrize("form", EXTEND_FORMS)
-def test_extend_long_prefix(form, monkeypatch):
-    _force_extend_form(monkeypatch, form)
+def test_extend_long_prefix(form, variants):
+    _force_extend_form(variants, form)
     case = build_extend_case(16, 8, 16, [2048, 0], [130, 700], seed=21)
     check_extend(case, run_extend(case, 16))
 
 
 @pytest.mark.parametrize("form", EXTEND_FORMS)
-def test_extend_scores_that_grow_along_the_keys(form, monkeypatch):
+def test_extend_scores_that_grow_along_the_keys(form, variants):
     """Online-softmax bookkeeping under a running maximum that keeps moving: the keys come in bands of 256 positions
     whose rows are scaled by 1, 3, 1, 14, 1, 40, 80, so the row maxima jump by a few units (below the growth at which
     the four-wave kernel moves its reference maximum: probabilities above 1), by tens of units (every kernel rescales
     its output accumulators in the middle of its steady state), and again inside the rows' own causal range."""
-    _force_extend_form(monkeypatch, form)
+    _force_extend_form(variants, form)
     ps = 16
     prefix, inputs = [1536, 256 + 32], [384, 300]
     case = build_extend_case(8, 2, ps, prefix, inputs, seed=77)
@@ -435,23 +435,23 @@ def test_extend_scores_that_grow_along_the_keys(form, monkeypatch):
 
 
 @pytest.mark.parametrize("form", EXTEND_FORMS)
-def test_extend_few_queries_on_long_unaligned_prefixes(form, monkeypatch):
+def test_extend_few_queries_on_long_unaligned_prefixes(form, variants):
     """Decode-like calls through the extend entry point (chunked prefill tails): 1-5 new tokens on prefixes that are
     not multiples of the 64-key tile, so almost every wave of the work group has nothing to do."""
-    _force_extend_form(monkeypatch, form)
+    _force_extend_form(variants, form)
     case = build_extend_case(8, 2, 1, [4097, 33, 63, 64, 0], [1, 5, 2, 1, 1], seed=41)
     check_extend(case, run_extend(case, 1))
 
 
 @pytest.mark.parametrize("Hq,Hkv,forced", [(8, 1, None), (8, 1, "3"), (2, 1, None), (4, 4, "2")])
-def test_extend_key_split_matches_unsplit_and_oracle(Hq, Hkv, forced, monkeypatch):
+def test_extend_key_split_matches_unsplit_and_oracle(Hq, Hkv, forced, variants):
     """Few work items over long key ranges: with a workspace the keys of every item are cut into runs, one work group
     each, and joined by a second kernel.  Compared with the oracle and with the unsplit launch (which sums the same
     products in another order: fp32 rounding only).  Covers runs that end before a row's first visible key, runs
     that are empty for the early query tiles, prefixes that are no multiple of a key tile, and ragged batches."""
     ops = _ops()
     if forced:
-        monkeypatch.setenv("MSGL_EXTEND_KSPLIT", forced)
+        variants("extend_key_split", forced)
     ps = 16
     prefix, inputs = [2048 + 16 * 3, 0, 4096], [200, 2300, 1]
     case = build_extend_case(Hq, Hkv, ps, prefix, inputs, seed=61 + Hq)
@@ -468,7 +468,7 @@ def test_extend_key_split_matches_unsplit_and_oracle(Hq, Hkv, forced, monkeypatc
 
 @pytest.mark.parametrize("Hq,Hkv", [(16, 8), (32, 8), (8, 1), (4, 4)])
 @pytest.mark.parametrize("page_size", [1, 16])
-def test_extend_short_requests_two_slot_kernel(Hq, Hkv, page_size, monkeypatch):
+def test_extend_short_requests_two_slot_kernel(Hq, Hkv, page_size, variants):
     """With the longest request announced (max_seqlen_k) and short, the library takes the kernel with a two-slot
     ring and one head per work group; 0 (unknown) takes a three-slot one.  Same oracle, same bar.  The two-slot and
     the eight-wave three-slot kernel agree to the last bit (same arithmetic in the same order, only the staging
@@ -485,7 +485,7 @@ def test_extend_short_requests_two_slot_kernel(Hq, Hkv, page_size, monkeypatch):
     wide = run_extend(case, ps, max_seqlen_k=0)
     check_extend(case, wide)
     assert (wide.float() - out.float()).abs().max().item() <= 1e-2
-    monkeypatch.setenv("MSGL_EXTEND_WIDE", "0")
+    variants("extend_wide", "0")
     assert torch.equal(out, run_extend(case, ps, max_seqlen_k=0))
 
 
@@ -512,10 +512,10 @@ def test_extend_plan_orders_items_longest_first():
 
 
 @pytest.mark.parametrize("forced_ring", [None, "2"])
-def test_extend_planned_launch_is_bit_identical(forced_ring, monkeypatch):
+def test_extend_planned_launch_is_bit_identical(forced_ring, variants):
     """The plan only permutes work groups: same bits with and without it, on a ragged batch with shared shapes."""
     if forced_ring:
-        monkeypatch.setenv("MSGL_EXTEND_ST", forced_ring)
+        variants("extend_ring", forced_ring)
     case = build_extend_case(16, 8, 16, [0, 1024, 0, 2048, 0, 16], [100, 300, 900, 50, 1, 128], seed=51)
     base = run_extend(case, 16)
     check_extend(case, base)

@@ -58,7 +58,7 @@ def test_decode_shared_prefix_random_case(seed):
 
 
 @pytest.mark.parametrize("seed", range(20 + MORE))
-def test_extend_random_case(seed, monkeypatch):
+def test_extend_random_case(seed, variants):
     rng = random.Random(3000 + seed)
     Hq, Hkv = rng.choice([(32, 8), (16, 8), (8, 1), (4, 1), (4, 4), (16, 4)])
     ps = rng.choice([1, 16, 64])
@@ -75,5 +75,5 @@ def test_extend_random_case(seed, monkeypatch):
     hinted = tk.run_extend(case, ps, max_seqlen_k=kmax, planned=True)
     tk.check_extend(case, hinted)
     assert (hinted.float() - base.float()).abs().max().item() <= 1e-2
-    monkeypatch.setenv("MSGL_EXTEND_WIDE", "0")
+    variants("extend_wide", "0")
     assert torch.equal(tk.run_extend(case, ps, max_seqlen_k=kmax, planned=True), tk.run_extend(case, ps))

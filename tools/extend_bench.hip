@@ -4,7 +4,7 @@
 // Built with -DEXT_STAMPS against a library object built the same way it also prints the cycles the steady-state
 // loop of the prefill kernel spends per segment (see scripts/stamp_extend.sh).
 //
-//   extend_bench [--bs 2] [--sq 8192] [--prefix 0] [--ps 16] [--hq 32] [--hkv 8] [--steps 10] [--warmup 2]
+//   extend_bench [--bs 2] [--sq 8192] [--prefix 0] [--ps 16] [--hq 32] [--hkv 8] [--steps 10] [--warmup 2] [--heads 1|2] [--wide 0|1] [--ring 2|3] [--ksplit 1..8]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -56,6 +56,11 @@ int main(int argc, char** argv) {
         else if (a == "--hkv") hkv = v;
         else if (a == "--steps") steps = v;
         else if (a == "--warmup") warmup = v;
+        // kernel-form overrides (msgl_set_variant): what the library would otherwise choose from the shape
+        else if (a == "--heads") msgl_set_variant(MSGL_VARIANT_EXTEND_HEADS, v);
+        else if (a == "--wide") msgl_set_variant(MSGL_VARIANT_EXTEND_WIDE, v);
+        else if (a == "--ring") msgl_set_variant(MSGL_VARIANT_EXTEND_RING, v);
+        else if (a == "--ksplit") msgl_set_variant(MSGL_VARIANT_EXTEND_KEY_SPLIT, v);
         else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
     }
     const int D = 128;
