@@ -40,6 +40,40 @@ def trace(msg):
 _T0 = time.perf_counter()
 
 
+def spread(samples, digits=4):
+    """Median and range of a list of timings: {"median": ., "min": ., "max": ., "n": .}."""
+    v = sorted(samples)
+    n = len(v)
+    med = v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+    return {"median": round(med, digits), "min": round(v[0], digits), "max": round(v[-1], digits), "n": n}
+
+
+def time_graph(f, launches, reps=7, warm=2):
+    """Per-launch device milliseconds of f(i), i = 0 .. launches-1, captured in one hipGraph (as a serving loop replays
+    its launches: a kernel of a few microseconds is otherwise timed together with the host's launch gaps) and replayed
+    `reps` times, each replay between its own pair of HIP events on the replay stream.  Returns the list of reps
+    per-launch times."""
+    for i in range(min(launches, 4)):
+        f(i)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(launches):
+            f(i)
+    for _ in range(warm):
+        g.replay()
+    torch.cuda.synchronize()
+    out = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) / launches)
+    return out
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,10 +94,11 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the full-model decode tok/s measurement")
     ap.add_argument("--no-extend", action="store_true", help="skip the prefill-attention TFLOP/s measurement")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary decode-attention configurations")
+    ap.add_argument("--no-layers", action="store_true", help="skip the layer-kernel (norm / activation / rotary / store) measurements")
     ap.add_argument("--secondary-deadline", type=float, default=420.0,
                     help="seconds the measurements after the headline may take before the line is printed without them")
     ap.add_argument("--e2e-ctx", type=int, default=0, help="0 = 8192 if the whole-model KV fits in HBM, else the largest power of two that does")
-    ap.add_argument("--e2e-steps", type=int, default=16)
+    ap.add_argument("--e2e-steps", type=int, default=20, help="timed whole-model decode steps (5 samples of a fifth each)")
     ap.add_argument("--e2e-eager", action="store_true", help="do not capture decode steps in hipGraphs")
     ap.add_argument("--mixed-bs", type=int, default=256, help="largest batch the mixed-length whole-model measurement tries")
     ap.add_argument("--allreduce-trial-child", action="store_true", help=argparse.SUPPRESS)
@@ -159,6 +194,7 @@ def main():
     per_step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     dev_ms_median = per_step_ms[len(per_step_ms) // 2] if len(per_step_ms) % 2 else 0.5 * (per_step_ms[len(per_step_ms) // 2 - 1] + per_step_ms[len(per_step_ms) // 2])
     dev_ms_mean = evs[0].elapsed_time(evs[-1]) / args.steps
+    dev_ms_median_rank = dev_ms_median
     if world > 1:
         import torch.distributed as dist
 
@@ -166,6 +202,9 @@ def main():
 
         elapsed, dev_ms_median, dev_ms_mean = (agree(v, "max", dev) for v in (elapsed, dev_ms_median, dev_ms_mean))
 
+    dist_info = None
+    if world > 1:
+        dist_info = describe_process_group(dev, dev_ms_median_rank)
     bytes_per_step_rank = 2 * Hkv * D * 2 * S * bs
     total_bytes = bytes_per_step_rank * world * args.steps
     value = total_bytes / elapsed / 1e9
@@ -203,29 +242,45 @@ def main():
             "launch_ms_stat": f"median of {args.steps} HIP-event intervals on the launch stream",
             "launch_ms_mean": round(dev_ms_mean, 4),
             "launch_ms_min_max": [round(per_step_ms[0], 4), round(per_step_ms[-1], 4)],
+            # the same two figures from the MEAN over the timed steps (what round 1 reported as achieved / frac)
+            "achieved_from_mean": round(bytes_per_step_rank / (dev_ms_mean * 1e-3) / 1e9, 1),
+            "frac_from_mean": round(bytes_per_step_rank / (dev_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "bytes_per_launch": bytes_per_step_rank,
         },
     }
 
+    if dist_info is not None:
+        result["distributed"] = dist_info
     # an on-box yardstick beside the spec peak: this library's read-only stream kernel (16 B per lane, non-temporal,
-    # nothing stored) over the first layer's pool, which is far larger than the caches
+    # nothing stored) over the first layer's pool, which is far larger than the caches; its rate depends on the loads
+    # in flight per lane and the resident work groups, so the best of a small sweep is quoted (round 1 quoted a
+    # device-to-device copy here, round 2 the single configuration (8, 16))
     try:
         buf = pools[0][0] if args.layout == "split" else pools[0][0]._base
         buf = buf.view(-1)
+        nbytes = buf.numel() * buf.element_size()
         sink = torch.zeros(64, dtype=torch.int32, device=dev)
-        for _ in range(2):
-            ops.stream_read(buf, sink)
-        c = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
-        c[0].record()
-        for i in range(5):
-            ops.stream_read(buf, sink)
-            c[i + 1].record()
-        torch.cuda.synchronize()
-        ts = sorted(c[i].elapsed_time(c[i + 1]) for i in range(5))
-        read_gbps = buf.numel() * buf.element_size() / (ts[2] * 1e-3) / 1e9
+        best, sweep = None, {}
+        for unroll, gpc in ((8, 16), (8, 8), (4, 8), (4, 16), (4, 32), (2, 16), (2, 32), (1, 32)):
+            for _ in range(2):
+                ops.stream_read(buf, sink, unroll, gpc)
+            c = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+            c[0].record()
+            for i in range(5):
+                ops.stream_read(buf, sink, unroll, gpc)
+                c[i + 1].record()
+            torch.cuda.synchronize()
+            ts = sorted(c[i].elapsed_time(c[i + 1]) for i in range(5))
+            gbps = nbytes / (ts[2] * 1e-3) / 1e9
+            sweep[f"unroll{unroll}_groups{gpc}"] = round(gbps, 1)
+            if best is None or gbps > best[0]:
+                best = (gbps, unroll, gpc)
+        read_gbps = best[0]
         result["roofline"]["measured_stream_read_GBps"] = round(read_gbps, 1)
-        result["roofline"]["stream_read_bytes"] = buf.numel() * buf.element_size()
+        result["roofline"]["stream_read_config"] = {"loads_in_flight_per_lane": best[1], "work_groups_per_cu": best[2], "sweep_GBps": sweep}
+        result["roofline"]["stream_read_bytes"] = nbytes
         result["roofline"]["frac_of_measured_stream_read"] = round(achieved / read_gbps, 4)
+        result["roofline"]["yardstick_changed_from"] = "r01: device-to-device copy (read + write); r02: read-only stream, one configuration; r03: best of a sweep"
     except Exception as e:
         result["roofline"]["measured_stream_read_error"] = f"{type(e).__name__}: {e}"[:120]
 
@@ -262,6 +317,9 @@ def main():
     if not args.no_extend:
         result["extend"] = extend_attention(args, world, rank)
         trace("extend done")
+    if not args.no_layers:
+        result["layers"] = layer_kernels(args, world, rank)
+        trace("layers done")
     xgmi_ok = False
     # ranks per physical GPU: 1 on a node with a GPU per rank, more in a one-GPU rehearsal, where every rank must
     # size its pools for its share of the memory it sees free
@@ -320,6 +378,30 @@ def main():
         import torch.distributed as dist
 
         dist.destroy_process_group()
+
+
+def describe_process_group(dev, launch_ms_rank):
+    """What lets a reader check that an N > 1 line came from N ranks on N distinct GPUs: the process group's own
+    world size and backend, the RCCL version torch was built against, and, gathered over the ranks, every rank's
+    device identity (host / GPU UUID) and its own per-launch time."""
+    import torch.distributed as dist
+
+    from mini_sglang_amd.comm import tp_all_gather
+    from mini_sglang_amd.comm.xgmi_allreduce import _device_identity as device_identity
+
+    info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rank_launch_ms": None, "devices": None}
+    try:
+        v = torch.cuda.nccl.version()
+        info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:  # noqa: BLE001
+        info["rccl_version"] = f"unavailable ({type(e).__name__})"
+    ident = device_identity(dev).encode()[:96].ljust(96, b"\0")
+    mine = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
+    info["devices"] = [bytes(t.cpu().tolist()).rstrip(b"\0").decode("utf-8", "replace") for t in tp_all_gather(mine)]
+    info["distinct_devices"] = len(set(info["devices"]))
+    ms = torch.tensor([launch_ms_rank], dtype=torch.float64, device=dev).view(torch.uint8)
+    info["rank_launch_ms"] = [round(float(t.view(torch.float64)[0]), 4) for t in tp_all_gather(ms)]
+    return info
 
 
 def recorded_traffic(layout, bs, S, ps, Hq, Hkv):
@@ -410,26 +492,19 @@ def other_decode_configs(args, world, rank):
             ops.paged_decode(q, kv[:, 0], kv[:, 1], r2t, idx, sl, D ** -0.5, ps, out=o, workspace=ws, max_splits=ms,
                              chunk_tokens=chunk, reuse_lens=reuse, plan=plan)
 
-        for i in range(4):
-            f(i)
-        torch.cuda.synchronize()
-        # the launches of one timing pass are captured in a hipGraph, as a serving loop replays them: a 90 us kernel
-        # is otherwise timed together with the host's launch gaps
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for i in range(steps):
-                f(i)
-        g.replay()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        g.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) / steps * 1e-3
+        # the launches of one timing pass are captured in a hipGraph, as a serving loop replays them (a 20-90 us kernel
+        # is otherwise timed together with the host's launch gaps); 7 replays, each between its own events: median
+        per = time_graph(f, steps, reps=7)
+        sp = spread([x * 1e3 for x in per], 2)  # microseconds per launch
+        t = sp["median"] * 1e-6
         b = 2 * Hkv * D * 2
-        out[name] = {"GBps_per_gpu": round(b * sum(lens) / t / 1e9, 1), "unique_GBps_per_gpu": round(b * pt.unique_tokens / t / 1e9, 1),
-                     "ms_per_launch": round(t * 1e3, 4), "frac_of_hbm_peak": round(b * sum(lens) / t / 1e9 / HBM_PEAK_GBPS, 4),
+        algo, uniq = b * sum(lens) / t / 1e9, b * pt.unique_tokens / t / 1e9
+        out[name] = {"GBps_per_gpu": round(algo, 1), "unique_GBps_per_gpu": round(uniq, 1),
+                     "us_per_launch": sp, "ms_per_launch": round(t * 1e3, 4),
+                     # the roofline fraction is quoted on the bytes the kernel must move at least once (unique slots):
+                     # with radix-shared prefixes the algorithmic count (every request's whole context) exceeds them
+                     "frac_of_hbm_peak": round(uniq / HBM_PEAK_GBPS, 4),
+                     "algorithmic_GBps_over_peak": round(algo / HBM_PEAK_GBPS, 4),
                      "chunk_tokens": chunk, "planned_launch": plan is not None, "shared_prefix_once": cascade is not None}
 
     try:
@@ -485,16 +560,17 @@ def extend_attention(args, world, rank):
         for _ in range(3):
             f()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(steps):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        evs[0].record()
+        for i in range(steps):
             f()
-        e1.record()
+            evs[i + 1].record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / steps
+        sp = spread([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
+        ms = sp["median"]
         tf = 4 * Hq * D * Sq * (prefix + (Sq + 1) / 2) / (ms * 1e-3) / 1e12
         what = f"one {Sq}-token prompt" + (f" on a {prefix}-token cached prefix" if prefix else "")
-        return {"workload": f"{what}, {Hq} q / {Hkv} kv heads per GPU, page_size {ps}", "ms_per_launch": round(ms, 4), "key_split_workspace": ws is not None,
+        return {"workload": f"{what}, {Hq} q / {Hkv} kv heads per GPU, page_size {ps}", "ms_per_launch": round(ms, 4), "ms_per_launch_spread": sp, "key_split_workspace": ws is not None,
                 "TFLOPs_per_gpu": round(tf, 1),
                 "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4)}}
 
@@ -508,6 +584,105 @@ def extend_attention(args, world, rank):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def layer_kernels(args, world, rank):
+    """The fused layer kernels of the path (RMSNorm plain / fused-add / per-head, SiluAndMul, RoPE, the fused
+    q/k-norm + RoPE + KV store, the plain KV store) on Qwen3-8B shapes at prefill (16384 tokens) and decode (256 tokens)
+    sizes, this rank's shard under TP.  Per op: algorithmic bytes (every input element read once, every output element
+    written once), median device time per launch from 7 replays of a hipGraph of `launches` calls that rotate over
+    buffer sets larger than the 256 MiB Infinity Cache (prefill sizes; the decode-size tensors are a few MiB and stay
+    cache resident, as they are in a serving step right behind the GEMM that produced them), and the fraction of the
+    HBM peak.  One op (RMSNorm at the prefill size) also carries the CPU oracle's rate on the host cores."""
+    from mini_sglang_amd import ops
+    from mini_sglang_amd.layers.rotary_embedding import build_cos_sin_cache
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    hid, inter, Hq, Hkv, D = 4096, 12288 // world, args.hq // world, args.hkv // world, 128
+    out = {"shapes": f"Qwen3-8B, TP={world}: hidden {hid}, intermediate {inter}, {Hq} q / {Hkv} kv heads per GPU", "ops": {}}
+
+    def record(name, T, nbytes, f, launches):
+        per = time_graph(f, launches, reps=7)
+        sp = spread([x * 1e3 for x in per], 2)  # microseconds
+        gbps = nbytes / (sp["median"] * 1e-6) / 1e9
+        out["ops"][f"{name}_T{T}"] = {"bytes_per_launch": nbytes, "us_per_launch": sp, "GBps": round(gbps, 1),
+                                     "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4)}
+
+    try:
+        cache = build_cos_sin_cache(D, 40960, 1e6).to(dev)
+        w = (torch.randn(hid, device=dev) * 0.2 + 1).bfloat16()
+        wd = (torch.randn(D, device=dev) * 0.2 + 1).bfloat16()
+        for T in (16384, 256):
+            big = T > 1024
+            nb = 4 if big else 1                      # buffer sets cycled: 4 x (134 + 134) MB for [16384, 4096] in + out
+            launches = 8 if big else 32
+            xs = [torch.randn(T, hid, device=dev).bfloat16() for _ in range(nb)]
+            ys = [torch.empty_like(x) for x in xs]
+            record("rmsnorm", T, 2 * T * hid * 2 + hid * 2, lambda i: ops.rmsnorm(xs[i % nb], w, 1e-6, out=ys[i % nb]), launches)
+            record("fused_add_rmsnorm", T, 4 * T * hid * 2 + hid * 2, lambda i: ops.fused_add_rmsnorm(xs[i % nb], ys[i % nb], w, 1e-6), launches)
+            if big and rank == 0 and world == 1:
+                out["ops"][f"rmsnorm_T{T}"]["cpu_oracle"] = cpu_layer_baseline(xs[0], w)
+            del xs, ys
+            # per-head q/k norm as a stand-alone call: [T * (Hq + Hkv), 128] rows
+            rows = T * (Hq + Hkv)
+            hs = [torch.randn(rows, D, device=dev).bfloat16() for _ in range(nb)]
+            ho = [torch.empty_like(h) for h in hs]
+            record("rmsnorm_heads128", T, 2 * rows * D * 2 + D * 2, lambda i: ops.rmsnorm(hs[i % nb], wd, 1e-6, out=ho[i % nb]), launches)
+            del hs, ho
+            ng = 2 if big else 1                      # [16384, 2 x 12288] bf16 is 805 MB: two sets suffice
+            gs = [torch.randn(T, 2 * inter, device=dev).bfloat16() for _ in range(ng)]
+            go = [torch.empty(T, inter, device=dev, dtype=torch.bfloat16) for _ in range(ng)]
+            record("silu_and_mul", T, 3 * T * inter * 2, lambda i: ops.silu_and_mul(gs[i % ng], out=go[i % ng]), launches)
+            del gs, go
+            qkvs = [torch.randn(T, (Hq + 2 * Hkv) * D, device=dev).bfloat16() for _ in range(nb)]
+            pos = torch.randint(0, 40960, (T,), device=dev, dtype=torch.int32)
+
+            def rope(i):
+                t = qkvs[i % nb]
+                ops.rope_neox_(pos, t[:, : Hq * D], t[:, Hq * D: (Hq + Hkv) * D], cache, D)
+
+            record("rope_neox", T, 2 * T * (Hq + Hkv) * D * 2 + T * D * 4, rope, launches)
+            slots = T + 64
+            kvs = [torch.zeros(slots, 2, Hkv, D, device=dev, dtype=torch.bfloat16) for _ in range(nb)]
+            loc = (torch.randperm(slots - 16, device=dev)[:T] + 16).to(torch.int32)
+
+            def fused(i):
+                kv = kvs[i % nb]
+                ops.qknorm_rope_store_(qkvs[i % nb], wd, wd, 1e-6, pos, cache, Hq, Hkv, D, loc=loc, k_cache=kv[:, 0], v_cache=kv[:, 1])
+
+            # qkv row read once; q and k written back in place; k and v written to the pool; one cos/sin row per token
+            record("qknorm_rope_store", T, T * ((Hq + 2 * Hkv) * D * 2 + (Hq + Hkv) * D * 2 + 2 * Hkv * D * 2 + D * 4), fused, launches)
+
+            def store(i):
+                t, kv = qkvs[i % nb], kvs[i % nb]
+                ops.store_kv(t[:, Hq * D: (Hq + Hkv) * D].view(T, Hkv, D), t[:, (Hq + Hkv) * D:].view(T, Hkv, D), loc, kv[:, 0], kv[:, 1])
+
+            record("store_kv", T, T * (4 * Hkv * D * 2 + 4), store, launches)
+            del qkvs, kvs
+            torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_layer_baseline(x_dev, w_dev):
+    """The oracle's RMSNorm (layernorm.py:39-50 restated) on the host cores over the same [T, hidden] tensor."""
+    from oracle import torch_oracle as orc
+
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    cores = max(1, min(allowed, omp) if omp > 0 else allowed)
+    torch.set_num_threads(cores)
+    x, w = x_dev.cpu(), w_dev.cpu()
+    orc.rmsnorm_ref(x, w, 1e-6)
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or time.perf_counter() - t0 < 2.0:
+        orc.rmsnorm_ref(x, w, 1e-6)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"GBps": round(2 * x.numel() * 2 / dt / 1e9, 2), "ms": round(dt * 1e3, 1), "cores": cores, "kind": "port", "passes": reps}
+
+
 def decode_e2e_small(args, barrier):
     """Whole-model decode tok/s of the small configuration: Qwen3-0.6B shape, batch 64 x 2048 ctx, page_size 1
     (per-token page table, fully scattered slots), one GPU, hipGraph replay."""
@@ -515,12 +690,12 @@ def decode_e2e_small(args, barrier):
     from mini_sglang_amd.runtime.qwen3 import Qwen3Config
 
     try:
-        bs, ctx, ps, steps = 64, 2048, 1, 24
-        mr, batch = decode_loop.build_decode_state(Qwen3Config.qwen3_0_6b(), bs, ctx, ps, 2 * steps + 24, use_graph=not args.e2e_eager)
-        dt = decode_loop.time_decode(mr, batch, steps, 4, barrier=barrier)
+        bs, ctx, ps, samples, each = 64, 2048, 1, 6, 6
+        mr, batch = decode_loop.build_decode_state(Qwen3Config.qwen3_0_6b(), bs, ctx, ps, samples * each + 24, use_graph=not args.e2e_eager)
+        sp = spread([dt / each * 1e3 for dt in decode_loop.time_decode_samples(mr, batch, samples, each, 4, barrier=barrier)], 3)
         return {"model": "Qwen3-0.6B shape, random weights", "batch": bs, "ctx": ctx, "page_size": ps, "tp": 1,
-                "tok_per_s": round(bs * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-                "hip_graph": not args.e2e_eager}
+                "tok_per_s": round(bs / (sp["median"] * 1e-3), 1), "ms_per_step": sp["median"], "ms_per_step_spread": sp,
+                "steps": samples * each, "timing": f"median of {samples} samples of {each} steps", "hip_graph": not args.e2e_eager}
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -554,9 +729,11 @@ def decode_e2e_mixed(args, world, rank, barrier):
             if (unique + bs * 96) * per_token + 2 * 8.2e9 / world <= 0.8 * free or bs <= 16:
                 break
             bs //= 2
-        steps = 8
+        samples, each = 5, 2
+        steps = samples * each
         info = {"model": "Qwen3-8B shape, random weights", "batch": bs, "ctx": "log-uniform 1k-32k, 16 requests per shared 1-4k prefix",
-                "tokens_in_context": sum(lens), "page_size": ps, "tp": world, "steps": steps, "hip_graph": not args.e2e_eager}
+                "tokens_in_context": sum(lens), "page_size": ps, "tp": world, "steps": steps,
+                "timing": f"median of {samples} samples of {each} steps", "hip_graph": not args.e2e_eager}
         # every request reads its prefix itself, then: each group's prefix attended once per step (msgl_shared_prefix_decode)
         for suffix, share in (("", False), ("_prefix_once", True)):
             import gc
@@ -564,15 +741,15 @@ def decode_e2e_mixed(args, world, rank, barrier):
             mr, batch = decode_loop.build_decode_state(cfg, bs, 0, ps, 2 * steps + 24, use_graph=not args.e2e_eager, seq_lens=lens,
                                                        groups=groups, group_prefix_lens=prefix, share_prefix_in_graphs=share)
             mr.attn_backend.share_prefix_reads = share
-            dt = decode_loop.time_decode(mr, batch, steps, 3, barrier=barrier)
+            dts = decode_loop.time_decode_samples(mr, batch, samples, each, 3, barrier=barrier)
             if world > 1:
-                import torch.distributed as dist
-
                 from mini_sglang_amd.comm import agree
 
-                dt = agree(dt, "max", "cuda")
-            info["tok_per_s" + suffix] = round(bs * steps / dt, 1)
-            info["ms_per_step" + suffix] = round(dt / steps * 1e3, 3)
+                dts = [agree(dt, "max", "cuda") for dt in dts]
+            sp = spread([dt / each * 1e3 for dt in dts], 3)
+            info["tok_per_s" + suffix] = round(bs / (sp["median"] * 1e-3), 1)
+            info["ms_per_step" + suffix] = sp["median"]
+            info["ms_per_step_spread" + suffix] = sp
             del mr, batch
             gc.collect()
             torch.cuda.empty_cache()
@@ -598,7 +775,7 @@ def decode_e2e(args, world, rank, barrier):
         ctx = args.e2e_ctx
         if ctx <= 0:
             ctx = 8192
-            while ctx > 256 and bs * (ctx + 64) * per_token + weights > 0.85 * free:
+            while ctx > 256 and bs * (ctx + 160) * per_token + weights > 0.85 * free:
                 ctx //= 2
             if world > 1:  # every rank must build the same page tables: agree on the smallest choice
                 import torch.distributed as dist
@@ -609,30 +786,32 @@ def decode_e2e(args, world, rank, barrier):
         info = {"model": "Qwen3-8B shape, random weights", "batch": bs, "ctx": ctx, "page_size": ps, "tp": world}
         use_graph = not args.e2e_eager
         try:
-            mr, batch = decode_loop.build_decode_state(cfg, bs, ctx, ps, 2 * args.e2e_steps + 24, use_graph=use_graph)
+            mr, batch = decode_loop.build_decode_state(cfg, bs, ctx, ps, args.e2e_steps + 5 * 8 + 40, use_graph=use_graph)
         except Exception as e:  # graph capture refused (e.g. a collective that cannot be captured): run eagerly
             if not use_graph:
                 raise
             info["graph_error"] = f"{type(e).__name__}: {e}"[:200]
             use_graph = False
             torch.cuda.synchronize()
-            mr, batch = decode_loop.build_decode_state(cfg, bs, ctx, ps, 2 * args.e2e_steps + 24, use_graph=False)
-        dt = decode_loop.time_decode(mr, batch, args.e2e_steps, 4, barrier=barrier)
+            mr, batch = decode_loop.build_decode_state(cfg, bs, ctx, ps, args.e2e_steps + 5 * 8 + 40, use_graph=False)
+        samples = 5
+        each = max(1, args.e2e_steps // samples)
+        dts = decode_loop.time_decode_samples(mr, batch, samples, each, 4, barrier=barrier)
         if world > 1:
-            import torch.distributed as dist  # noqa: F811
-
             from mini_sglang_amd.comm import agree
 
-            dt = agree(dt, "max", "cuda")
-        info.update({"tok_per_s": round(bs * args.e2e_steps / dt, 1), "ms_per_step": round(dt / args.e2e_steps * 1e3, 3),
-                     "steps": args.e2e_steps, "hip_graph": use_graph})
+            dts = [agree(dt, "max", "cuda") for dt in dts]
+        sp = spread([dt / each * 1e3 for dt in dts], 3)
+        info.update({"tok_per_s": round(bs / (sp["median"] * 1e-3), 1), "ms_per_step": sp["median"], "ms_per_step_spread": sp,
+                     "steps": samples * each, "timing": f"median of {samples} samples of {each} steps", "hip_graph": use_graph})
         if use_graph:
             try:  # the same steps chained on the device, 8 per host synchronisation
-                dt = decode_loop.time_decode_chained(mr, batch, args.e2e_steps, 2, chain=8, barrier=barrier)
+                dts = decode_loop.time_decode_chained_samples(mr, batch, samples, 8, 2, barrier=barrier)
                 if world > 1:
-                    dt = agree(dt, "max", "cuda")
-                info.update({"tok_per_s_chained": round(bs * args.e2e_steps / dt, 1),
-                             "ms_per_step_chained": round(dt / args.e2e_steps * 1e3, 3), "chain": 8})
+                    dts = [agree(dt, "max", "cuda") for dt in dts]
+                sp = spread([dt / 8 * 1e3 for dt in dts], 3)
+                info.update({"tok_per_s_chained": round(bs / (sp["median"] * 1e-3), 1), "ms_per_step_chained": sp["median"],
+                             "ms_per_step_chained_spread": sp, "chain": 8})
             except Exception as e:
                 info["chained_error"] = f"{type(e).__name__}: {e}"[:200]
         return info

@@ -362,6 +362,10 @@ int msgl_prepare_decode(const int32_t* req_pool_indices, int32_t* seq_lens, int3
  * the on-box read-only streaming rate beside the decode kernel's.
  * ------------------------------------------------------------------------- */
 int msgl_stream_read(const void* src, size_t bytes, void* sink, void* stream);
+/* The same with the kernel's two tuning knobs exposed: unroll = 16-byte loads in flight per lane (1, 2, 4 or 8),
+ * groups_per_cu = resident 256-thread work groups per compute unit the grid is capped at (1..64).
+ * msgl_stream_read is (8, 16).  bench.py sweeps a few pairs and quotes the best as its yardstick. */
+int msgl_stream_read_cfg(const void* src, size_t bytes, void* sink, int unroll, int groups_per_cu, void* stream);
 
 #ifdef __cplusplus
 }

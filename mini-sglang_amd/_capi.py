@@ -72,6 +72,7 @@ SIGNATURES = {
          c_void_p, c_void_p, c_int, c_int, c_void_p],
     ),
     "msgl_stream_read": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "msgl_stream_read_cfg": (c_int, [c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p]),
     # include/msgl_comm.h
     "msgl_ar_create": (c_int, [c_int, c_int, c_size_t, ctypes.POINTER(c_void_p)]),
     "msgl_ar_export": (c_int, [c_void_p, c_void_p]),

@@ -164,7 +164,11 @@ def tp_all_reduce(t: torch.Tensor) -> torch.Tensor:
     if _active is not None and _active.fits(t):
         return _active.all_reduce(t)
     if t.is_cuda and _host_side_backend():
-        h = t.float().cpu()
+        # (rehearsals on a CPU-side backend only) 16-bit floats are summed in fp32 and rounded once, as the direct-read
+        # kernels do; every other dtype, integers included, is reduced as it is
+        h = t.cpu()
+        if h.dtype in (torch.bfloat16, torch.float16):
+            h = h.float()
         dist.all_reduce(h)
         t.copy_(h)
         return t

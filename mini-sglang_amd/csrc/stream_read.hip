@@ -1,24 +1,26 @@
-// Read-only streaming yardstick for the benchmark: every byte of a buffer is loaded once, 16 bytes per lane,
-// eight loads in flight per lane, nothing is stored (one word per work group at most).  What a kernel that only
-// reads HBM can reach on this box, next to which the decode kernel's gather is quoted.
+// Read-only streaming yardstick for the benchmark: every byte of a buffer is loaded once, 16 bytes per lane, with
+// `UNROLL` loads in flight per lane, nothing is stored (one word per work group at most).  What a kernel that only
+// reads HBM can reach on this box, next to which the decode kernel's gather is quoted.  The rate depends on the
+// loads in flight per lane and on the number of resident work groups, so both are arguments of the _cfg entry point
+// and the benchmark quotes the best of a small sweep.
 #include "msgl_common.h"
 
 namespace msgl {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int su32x4_t;
 constexpr int kStreamThreads = 256;
-constexpr int kStreamUnroll = 8;
 
+template <int UNROLL>
 __global__ __launch_bounds__(kStreamThreads) void stream_read_kernel(const su32x4_t* __restrict__ src, int64_t nvec, uint32_t* __restrict__ sink) {
     const int64_t stride = (int64_t)gridDim.x * kStreamThreads;
     int64_t i = (int64_t)blockIdx.x * kStreamThreads + threadIdx.x;
     su32x4_t acc = {0u, 0u, 0u, 0u};
-    for (; i + (kStreamUnroll - 1) * stride < nvec; i += kStreamUnroll * stride) {
-        su32x4_t v[kStreamUnroll];
+    for (; i + (UNROLL - 1) * stride < nvec; i += UNROLL * stride) {
+        su32x4_t v[UNROLL];
 #pragma unroll
-        for (int u = 0; u < kStreamUnroll; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+        for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
 #pragma unroll
-        for (int u = 0; u < kStreamUnroll; ++u) acc ^= v[u];
+        for (int u = 0; u < UNROLL; ++u) acc ^= v[u];
     }
     for (; i < nvec; i += stride) acc ^= __builtin_nontemporal_load(src + i);
     const uint32_t x = acc.x ^ acc.y ^ acc.z ^ acc.w;
@@ -30,14 +32,28 @@ __global__ __launch_bounds__(kStreamThreads) void stream_read_kernel(const su32x
 
 using namespace msgl;
 
-extern "C" int msgl_stream_read(const void* src, size_t bytes, void* sink, void* stream) {
+extern "C" int msgl_stream_read_cfg(const void* src, size_t bytes, void* sink, int unroll, int groups_per_cu, void* stream) {
     MSGL_REQUIRE(src && sink && aligned16(src), "msgl_stream_read: src must be a 16-byte aligned device pointer, sink 256 bytes of device memory");
     MSGL_REQUIRE(bytes >= 16 && bytes % 16 == 0, "msgl_stream_read: %zu bytes, a positive multiple of 16 expected", bytes);
+    MSGL_REQUIRE((unroll == 1 || unroll == 2 || unroll == 4 || unroll == 8) && groups_per_cu >= 1 && groups_per_cu <= 64,
+                 "msgl_stream_read: unroll %d (1, 2, 4 or 8), groups_per_cu %d (1..64)", unroll, groups_per_cu);
     const int64_t nvec = (int64_t)(bytes / 16);
-    int64_t blocks = (nvec + (int64_t)kStreamThreads * kStreamUnroll - 1) / ((int64_t)kStreamThreads * kStreamUnroll);
-    const int64_t cap = (int64_t)device_cus() * 16;  // grid-stride beyond that: 16 work groups per compute unit
+    int64_t blocks = (nvec + (int64_t)kStreamThreads * unroll - 1) / ((int64_t)kStreamThreads * unroll);
+    const int64_t cap = (int64_t)device_cus() * groups_per_cu;  // grid-stride beyond that
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(stream_read_kernel, dim3((unsigned)blocks), dim3(kStreamThreads), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const su32x4_t*>(src), nvec, static_cast<uint32_t*>(sink));
+    const dim3 grid((unsigned)blocks), block(kStreamThreads);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const su32x4_t* s = static_cast<const su32x4_t*>(src);
+    uint32_t* k = static_cast<uint32_t*>(sink);
+    switch (unroll) {
+        case 1: hipLaunchKernelGGL(stream_read_kernel<1>, grid, block, 0, st, s, nvec, k); break;
+        case 2: hipLaunchKernelGGL(stream_read_kernel<2>, grid, block, 0, st, s, nvec, k); break;
+        case 4: hipLaunchKernelGGL(stream_read_kernel<4>, grid, block, 0, st, s, nvec, k); break;
+        default: hipLaunchKernelGGL(stream_read_kernel<8>, grid, block, 0, st, s, nvec, k); break;
+    }
     return check_launch("stream_read_kernel");
+}
+
+extern "C" int msgl_stream_read(const void* src, size_t bytes, void* sink, void* stream) {
+    return msgl_stream_read_cfg(src, bytes, sink, 8, 16, stream);
 }

@@ -571,7 +571,9 @@ def prepare_decode(req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, last_
         input_ids.data_ptr() if input_ids is not None else None, status.data_ptr(), bs, page_size, _stream()))
 
 
-def stream_read(buf: torch.Tensor, sink: torch.Tensor) -> None:
-    """Read every byte of `buf` once (16 B per lane, non-temporal) and store nothing: the benchmark's yardstick."""
+def stream_read(buf: torch.Tensor, sink: torch.Tensor, unroll: int = 8, groups_per_cu: int = 16) -> None:
+    """Read every byte of `buf` once (16 B per lane, non-temporal, `unroll` loads in flight per lane, at most
+    `groups_per_cu` work groups per compute unit) and store nothing: the benchmark's yardstick."""
     _need(buf.is_cuda and buf.is_contiguous() and sink.is_cuda and sink.numel() * sink.element_size() >= 256, "GPU buffers expected")
-    _check(_lib.msgl_stream_read(buf.data_ptr(), buf.numel() * buf.element_size() // 16 * 16, sink.data_ptr(), _stream()))
+    _check(_lib.msgl_stream_read_cfg(buf.data_ptr(), buf.numel() * buf.element_size() // 16 * 16, sink.data_ptr(), int(unroll),
+                                     int(groups_per_cu), _stream()))

@@ -116,3 +116,35 @@ def time_decode_chained(mr: ModelRunner, batch: BatchInfo, steps: int, warmup: i
         barrier()
     torch.cuda.synchronize()
     return time.perf_counter() - t0
+
+
+def time_decode_samples(mr: ModelRunner, batch: BatchInfo, samples: int, steps_each: int, warmup: int, barrier=None):
+    """`samples` consecutive timings of `steps_each` decode steps (as time_decode), after `warmup` untimed steps:
+    seconds per sample, in order (the contexts grow by a token per step, which the spread then includes)."""
+    out = [time_decode(mr, batch, steps_each, warmup, barrier=barrier)]
+    for _ in range(samples - 1):
+        out.append(time_decode(mr, batch, steps_each, 0, barrier=barrier))
+    return out
+
+
+def time_decode_chained_samples(mr: ModelRunner, batch: BatchInfo, samples: int, chain: int, warmup: int, barrier=None):
+    """`samples` timings of one device-side chain of `chain` decode steps each (see time_decode_chained)."""
+    from .device_decode import DeviceDecodeLoop
+
+    loop = DeviceDecodeLoop(mr, batch, max_steps=max(chain, warmup))
+    if warmup:
+        loop.run(warmup)
+        loop.sync_host()
+    out = []
+    for _ in range(samples):
+        if barrier is not None:
+            barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop.run(chain)
+        loop.sync_host()
+        if barrier is not None:
+            barrier()
+        torch.cuda.synchronize()
+        out.append(time.perf_counter() - t0)
+    return out

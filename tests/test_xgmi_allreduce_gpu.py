@@ -142,3 +142,9 @@ def test_bench_tensor_parallel_control_flow_end_to_end(tmp_path):
         assert "error" not in res[leg] and "skipped" not in res[leg] and res[leg]["tok_per_s"] > 0, (leg, res[leg])
         assert res[leg]["tp"] == 2 and res[leg]["hip_graph"] is False
     assert "error" not in res["other_configs"] and "error" not in res["extend"], (res["other_configs"], res["extend"])
+    assert "error" not in res["layers"] and res["layers"]["ops"], res["layers"]
+    # what lets a reader of a multi-GPU record check "N ranks on N distinct GPUs": here two ranks on ONE device
+    d = res["distributed"]
+    assert d["world_size"] == 2 and d["backend"] == "gloo" and "rccl_version" in d
+    assert len(d["devices"]) == 2 and d["devices"][0] == d["devices"][1] and d["distinct_devices"] == 1
+    assert len(d["rank_launch_ms"]) == 2 and all(ms > 0 for ms in d["rank_launch_ms"])
