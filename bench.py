@@ -432,6 +432,78 @@ def recorded_extend_counters(prompt, prefix, ps, Hq, Hkv):
             "matrix_core_busy_measured_at_commit": rec.get("commit"), "kernel": rec.get("kernel")}
 
 
+def mixed_radix_batch(bs=256):
+    """The mixed configuration of the benchmark family: `bs` contexts log-uniform in 1k-32k tokens (seed 3), groups of 16
+    requests on a shared page-aligned radix prefix of 1-4k tokens.  Returns (lens, groups, prefix_lens)."""
+    from mini_sglang_amd.runtime import workload
+
+    lens = workload.mixed_lengths(bs, 1024, 32768, 3)
+    groups = [i // 16 for i in range(bs)]
+    prefix = [1024 * (1 + g % 4) for g in range(bs // 16)]
+    lens = [max(n, prefix[g] + 16) for n, g in zip(lens, groups)]
+    return lens, groups, prefix
+
+
+def build_decode_config(Hq, Hkv, ps, lens, groups=None, prefix=None, layers=2, share_once=False, dev=None):
+    """One decode-attention configuration as HipAttnBackend launches it per layer: page table, per-layer pools of random
+    K/V, the split size / launch plan / shared-prefix arrays the backend would choose, and launch(i) = the call(s) of
+    layer i % layers.  The timed legs and the parity tests of the same shapes both go through this."""
+    from mini_sglang_amd import ops
+    from mini_sglang_amd.attn.hip_attn_backend import splits_for_batch
+    from mini_sglang_amd.runtime import workload
+
+    D = 128
+    dev = dev or torch.device("cuda", torch.cuda.current_device())
+    bs = len(lens)
+    pages = sum(-(-n // ps) for n in lens) + 8
+    pt = workload.make_page_table(lens, ps, pages, 3, groups=groups, group_prefix_lens=prefix)
+    slots = (pages + 1) * ps
+    pools = [torch.empty((slots, 2, Hkv, D), dtype=torch.bfloat16, device=dev).normal_() for _ in range(layers)]
+    q = torch.randn((bs, Hq, D), device=dev).bfloat16()
+    o = torch.empty_like(q)
+    r2t, sl = pt.req_to_token.to(dev), pt.seq_lens.to(dev)
+    idx = torch.arange(bs, dtype=torch.int32, device=dev)
+    ms = splits_for_batch(bs)
+    # what the backend does per step: ragged batches get the split size of the schedule model and a launch plan
+    ragged = max(lens) * bs > 1.25 * sum(lens)
+    chunk = ops.pick_split_planned(lens, ms, Hkv) if ragged else ops.pick_split(max(lens), sum(lens), bs, ms, Hkv)
+    ms = max(1, min(ms, -(-max(lens) // chunk)))
+    plan = ops.decode_plan(sl, ms, chunk) if ragged and ms > 1 else None  # once per step, shared by all layers
+    ws = torch.empty(max(16, ops.decode_workspace_bytes(bs, Hq, D, ms)), dtype=torch.uint8, device=dev)
+    reuse = torch.tensor([prefix[g] for g in groups], dtype=torch.int32, device=dev) if groups is not None else None
+
+    cascade = None
+    if groups is not None and share_once:
+        # the backend's eager path for such a batch: every group's prefix once through the matrix-core kernel
+        # (msgl_shared_prefix_decode), the private tails per request, one merge
+        ng = max(groups) + 1
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+        first, count = [groups.index(g) for g in range(ng)], [groups.count(g) for g in range(ng)]
+        key_chunk = 1024
+        start, extra = i32([prefix[g] for g in groups]), i32([-(-prefix[g] // key_chunk) for g in groups])
+        rest = [n - prefix[g] for n, g in zip(lens, groups)]
+        most_extra = max(-(-p_ // key_chunk) for p_ in prefix)
+        chunk = ops.pick_split_planned(rest, splits_for_batch(bs) - most_extra, Hkv)
+        ms = -(-max(rest) // chunk) + most_extra
+        ws = torch.empty(ops.decode_workspace_bytes(bs, Hq, D, ms), dtype=torch.uint8, device=dev)
+        plan = ops.decode_plan(sl, ms, chunk, start_lens=start)
+        cascade = (i32(first), i32(count), i32(prefix), max(count), max(prefix), key_chunk, start, extra)
+
+    def launch(i):
+        kv = pools[i % layers]
+        if cascade is not None:
+            gf, gc, gp, mm, mp, kc, start, extra = cascade
+            ops.shared_prefix_decode(q, kv[:, 0], kv[:, 1], r2t, idx, sl, start, gf, gc, gp, mm, mp, kc, D ** -0.5, ws, ms, chunk)
+            ops.paged_decode(q, kv[:, 0], kv[:, 1], r2t, idx, sl, D ** -0.5, ps, out=o, workspace=ws, max_splits=ms,
+                             chunk_tokens=chunk, plan=plan, start_lens=start, extra_splits=extra)
+            return
+        ops.paged_decode(q, kv[:, 0], kv[:, 1], r2t, idx, sl, D ** -0.5, ps, out=o, workspace=ws, max_splits=ms,
+                         chunk_tokens=chunk, reuse_lens=reuse, plan=plan)
+
+    return {"launch": launch, "q": q, "out": o, "pools": pools, "page_table": pt, "req_to_token": r2t, "seq_lens": sl,
+            "req_idx": idx, "chunk": chunk, "max_splits": ms, "plan": plan, "cascade": cascade, "workspace": ws, "reuse_lens": reuse}
+
+
 def other_decode_configs(args, world, rank):
     """Decode attention (one layer per launch, same accounting as the headline: algorithmic KV bytes, no
     de-duplication of shared prefixes) on the other single-layer shapes the benchmark family names: Qwen3-0.6B
@@ -446,52 +518,8 @@ def other_decode_configs(args, world, rank):
     out = {}
 
     def run(name, Hq, Hkv, ps, lens, groups=None, prefix=None, layers=2, steps=12, share_once=False):
-        bs = len(lens)
-        pages = sum(-(-n // ps) for n in lens) + 8
-        pt = workload.make_page_table(lens, ps, pages, 3, groups=groups, group_prefix_lens=prefix)
-        slots = (pages + 1) * ps
-        pools = [torch.empty((slots, 2, Hkv, D), dtype=torch.bfloat16, device=dev).normal_() for _ in range(layers)]
-        q = torch.randn((bs, Hq, D), device=dev).bfloat16()
-        o = torch.empty_like(q)
-        r2t, sl = pt.req_to_token.to(dev), pt.seq_lens.to(dev)
-        idx = torch.arange(bs, dtype=torch.int32, device=dev)
-        ms = splits_for_batch(bs)
-        # what the backend does per step: ragged batches get the split size of the schedule model and a launch plan
-        ragged = max(lens) * bs > 1.25 * sum(lens)
-        chunk = ops.pick_split_planned(lens, ms, Hkv) if ragged else ops.pick_split(max(lens), sum(lens), bs, ms, Hkv)
-        ms = max(1, min(ms, -(-max(lens) // chunk)))
-        plan = ops.decode_plan(sl, ms, chunk) if ragged and ms > 1 else None  # once per step, shared by all layers
-        ws = torch.empty(max(16, ops.decode_workspace_bytes(bs, Hq, D, ms)), dtype=torch.uint8, device=dev)
-        reuse = torch.tensor([prefix[g] for g in groups], dtype=torch.int32, device=dev) if groups is not None else None
-
-        cascade = None
-        if groups is not None and share_once:
-            # the backend's eager path for such a batch: every group's prefix once through the matrix-core kernel
-            # (msgl_shared_prefix_decode), the private tails per request, one merge
-            ng = max(groups) + 1
-            i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
-            first, count = [groups.index(g) for g in range(ng)], [groups.count(g) for g in range(ng)]
-            key_chunk = 1024
-            start, extra = i32([prefix[g] for g in groups]), i32([-(-prefix[g] // key_chunk) for g in groups])
-            rest = [n - prefix[g] for n, g in zip(lens, groups)]
-            most_extra = max(-(-p_ // key_chunk) for p_ in prefix)
-            chunk = ops.pick_split_planned(rest, splits_for_batch(bs) - most_extra, Hkv)
-            ms = -(-max(rest) // chunk) + most_extra
-            ws = torch.empty(ops.decode_workspace_bytes(bs, Hq, D, ms), dtype=torch.uint8, device=dev)
-            plan = ops.decode_plan(sl, ms, chunk, start_lens=start)
-            cascade = (i32(first), i32(count), i32(prefix), max(count), max(prefix), key_chunk, start, extra)
-
-        def f(i):
-            kv = pools[i % layers]
-            if cascade is not None:
-                gf, gc, gp, mm, mp, kc, start, extra = cascade
-                ops.shared_prefix_decode(q, kv[:, 0], kv[:, 1], r2t, idx, sl, start, gf, gc, gp, mm, mp, kc, D ** -0.5, ws, ms, chunk)
-                ops.paged_decode(q, kv[:, 0], kv[:, 1], r2t, idx, sl, D ** -0.5, ps, out=o, workspace=ws, max_splits=ms,
-                                 chunk_tokens=chunk, plan=plan, start_lens=start, extra_splits=extra)
-                return
-            ops.paged_decode(q, kv[:, 0], kv[:, 1], r2t, idx, sl, D ** -0.5, ps, out=o, workspace=ws, max_splits=ms,
-                             chunk_tokens=chunk, reuse_lens=reuse, plan=plan)
-
+        cfg = build_decode_config(Hq, Hkv, ps, lens, groups, prefix, layers, share_once, dev)
+        f, pt, chunk, plan, cascade = cfg["launch"], cfg["page_table"], cfg["chunk"], cfg["plan"], cfg["cascade"]
         # the launches of one timing pass are captured in a hipGraph, as a serving loop replays them (a 20-90 us kernel
         # is otherwise timed together with the host's launch gaps); 7 replays, each between its own events: median
         per = time_graph(f, steps, reps=7)
@@ -513,10 +541,7 @@ def other_decode_configs(args, world, rank):
             # the long-context configuration: one TP-8 shard of Qwen3-32B (8 q / 1 kv head), page_size 64, 128k contexts
             run("qwen3_32b_tp8_shard_bs1_ctx131072_ps64", 8, 1, 64, [131072], layers=8, steps=20)
             run("qwen3_32b_tp8_shard_bs8_ctx131072_ps64", 8, 1, 64, [131072] * 8, layers=4, steps=12)
-        lens = workload.mixed_lengths(256, 1024, 32768, 3)
-        groups = [i // 16 for i in range(256)]
-        prefix = [1024 * (1 + g % 4) for g in range(16)]
-        lens = [max(n, prefix[g] + 16) for n, g in zip(lens, groups)]
+        lens, groups, prefix = mixed_radix_batch(256)
         run("qwen3_8b_bs256_mixed_1k_32k_ps16_radix_shared", args.hq // world, args.hkv // world, 16, lens, groups, prefix)
         run("qwen3_8b_bs256_mixed_1k_32k_ps16_radix_shared_prefix_once", args.hq // world, args.hkv // world, 16, lens, groups, prefix,
             share_once=True)
@@ -524,6 +549,36 @@ def other_decode_configs(args, world, rank):
         out["error"] = f"{type(e).__name__}: {e}"[:300]
     torch.cuda.empty_cache()
     return out
+
+
+def build_extend_config(Hq, Hkv, ps, Sq, prefix, seed=31, dev=None):
+    """One prefill-attention launch as HipAttnBackend.forward_extend issues it: a single request of `Sq` new tokens on a
+    `prefix`-token cached prefix, scattered pages, and -- when the launch has fewer work items (128-row query tiles x
+    head pairs) than compute units over a long key range -- the workspace that lets the library cut the items' keys
+    into runs.  The timed legs and the parity tests of the same shapes both go through this."""
+    from mini_sglang_amd import ops
+    from mini_sglang_amd.runtime import synth, workload
+
+    D = 128
+    dev = dev or torch.device("cuda", torch.cuda.current_device())
+    S = prefix + Sq
+    pages = -(-S // ps) + 8
+    pt = workload.make_page_table([S], ps, pages, seed=5, scatter=True)
+    kv = synth.normal(((pages + 1) * ps, 2, Hkv, D), seed, device=dev)
+    q = synth.normal((Sq, Hq, D), seed + 1, device=dev)
+    out = torch.empty_like(q)
+    r2t = pt.req_to_token.to(dev)
+    idx = torch.zeros(1, dtype=torch.int32, device=dev)
+    cu = torch.tensor([0, Sq], dtype=torch.int32, device=dev)
+    pre = torch.tensor([prefix], dtype=torch.int32, device=dev)
+    ws = None
+    if -(-Sq // 128) * max(1, Hq // 2) < torch.cuda.get_device_properties(dev).multi_processor_count and S >= 2048:
+        ws = torch.empty(ops.extend_workspace_bytes(Sq, Hq, D), dtype=torch.uint8, device=dev)
+
+    def launch():
+        ops.paged_extend(q, kv[:, 0], kv[:, 1], r2t, idx, cu, pre, Sq, D ** -0.5, ps, out=out, max_seqlen_k=S, workspace=ws)
+
+    return {"launch": launch, "q": q, "kv": kv, "out": out, "req_to_token": r2t, "page_table": pt, "workspace": ws}
 
 
 def extend_attention(args, world, rank):
@@ -537,26 +592,8 @@ def extend_attention(args, world, rank):
     dev = torch.device("cuda", torch.cuda.current_device())
 
     def measure(Hq, Hkv, ps, Sq, prefix, steps=10):
-        S = prefix + Sq
-        pages = -(-S // ps) + 8
-        pt = workload.make_page_table([S], ps, pages, seed=5, scatter=True)
-        kv = synth.normal(((pages + 1) * ps, 2, Hkv, D), 31 + rank, device=dev)
-        q = synth.normal((Sq, Hq, D), 32 + rank, device=dev)
-        out = torch.empty_like(q)
-        r2t = pt.req_to_token.to(dev)
-        idx = torch.zeros(1, dtype=torch.int32, device=dev)
-        cu = torch.tensor([0, Sq], dtype=torch.int32, device=dev)
-        pre = torch.tensor([prefix], dtype=torch.int32, device=dev)
-
-        # as HipAttnBackend.forward_extend does: a launch of fewer work items (128-row query tiles x head pairs) than
-        # compute units gets a workspace, and the library cuts the items' key ranges into runs
-        ws = None
-        if -(-Sq // 128) * max(1, Hq // 2) < torch.cuda.get_device_properties(dev).multi_processor_count and S >= 2048:
-            ws = torch.empty(ops.extend_workspace_bytes(Sq, Hq, D), dtype=torch.uint8, device=dev)
-
-        def f():
-            ops.paged_extend(q, kv[:, 0], kv[:, 1], r2t, idx, cu, pre, Sq, D ** -0.5, ps, out=out, max_seqlen_k=S, workspace=ws)
-
+        cfg = build_extend_config(Hq, Hkv, ps, Sq, prefix, seed=31 + rank, dev=dev)
+        f, ws = cfg["launch"], cfg["workspace"]
         for _ in range(3):
             f()
         torch.cuda.synchronize()
@@ -590,8 +627,9 @@ def layer_kernels(args, world, rank):
     sizes, this rank's shard under TP.  Per op: algorithmic bytes (every input element read once, every output element
     written once), median device time per launch from 7 replays of a hipGraph of `launches` calls that rotate over
     buffer sets larger than the 256 MiB Infinity Cache (prefill sizes; the decode-size tensors are a few MiB and stay
-    cache resident, as they are in a serving step right behind the GEMM that produced them), and the fraction of the
-    HBM peak.  One op (RMSNorm at the prefill size) also carries the CPU oracle's rate on the host cores."""
+    cache resident, as they are in a serving step right behind the GEMM that produced them, and their times are launch
+    latency, not bandwidth), and the fraction of the HBM peak.  KV slots are whole pages of `--page-size` tokens in
+    random order, as the allocator hands them to a prefill.  One op (RMSNorm at the prefill size) also carries the CPU oracle's rate on the host cores."""
     from mini_sglang_amd import ops
     from mini_sglang_amd.layers.rotary_embedding import build_cos_sin_cache
 
@@ -640,9 +678,13 @@ def layer_kernels(args, world, rank):
                 ops.rope_neox_(pos, t[:, : Hq * D], t[:, Hq * D: (Hq + Hkv) * D], cache, D)
 
             record("rope_neox", T, 2 * T * (Hq + Hkv) * D * 2 + T * D * 4, rope, launches)
-            slots = T + 64
+            # slots as the page allocator hands them to a prefill: whole pages in random order, consecutive slots inside
+            ps = args.page_size
+            n_pages = -(-T // ps)
+            slots = (n_pages + 5) * ps
             kvs = [torch.zeros(slots, 2, Hkv, D, device=dev, dtype=torch.bfloat16) for _ in range(nb)]
-            loc = (torch.randperm(slots - 16, device=dev)[:T] + 16).to(torch.int32)
+            page_of = (torch.randperm(n_pages + 4, device=dev)[:n_pages] + 1).repeat_interleave(ps)[:T]
+            loc = (page_of * ps + torch.arange(T, device=dev) % ps).to(torch.int32)
 
             def fused(i):
                 kv = kvs[i % nb]

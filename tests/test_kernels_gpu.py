@@ -694,6 +694,101 @@ def test_argmax():
         assert torch.equal(val.cpu().nan_to_num(nan=123.0), want.nan_to_num(nan=123.0)), "the winning logit itself, bit for bit"
 
 
+# The layer kernels take other forms at prefill sizes (a wave per row, several rows / heads / tokens per lane group,
+# non-temporal accesses for tensors far beyond the caches); same oracle, same bounds.  Odd row counts exercise the tails.
+@pytest.mark.parametrize("cols", [1024, 2048, 2560, 4096, 5120, 8192])
+def test_rmsnorm_many_rows(cols):
+    ops = _ops()
+    synth, _ = _synth()
+    rows = 4099
+    x, r = synth.normal((rows, cols), 41, std=2.0), synth.normal((rows, cols), 42, std=3.0)
+    w = synth.normal((cols,), 43, std=0.5) + 1
+    d = ulp_diff_bf16(ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-6).cpu(), orc.rmsnorm_ref(x, w, 1e-6))
+    assert d.max() <= 1 and (d > 0).float().mean() < 0.02, (d.max(), (d > 0).float().mean())
+    y_ref, r_ref = orc.rmsnorm_ref(x, w, 1e-6, residual=r)
+    xd, rd = x.to(DEV), r.to(DEV)
+    ops.fused_add_rmsnorm(xd, rd, w.to(DEV), 1e-6)
+    assert torch.equal(rd.cpu(), r_ref), "residual' = bf16(x + residual) must be bit exact"
+    d = ulp_diff_bf16(xd.cpu(), y_ref)
+    assert d.max() <= 1 and (d > 0).float().mean() < 0.02
+
+
+def test_rmsnorm_streamed_sizes():
+    """[16384 + 3, 4096] plain (in + out >= 512 MiB: non-temporal form) and fused-add, and 128-wide head rows beyond
+    the count at which a lane group takes four rows, strided as the q part of a qkv buffer."""
+    ops = _ops()
+    synth, _ = _synth()
+    rows, cols = 16387, 4096
+    x, r = synth.normal((rows, cols), 44, std=2.0, device=DEV), synth.normal((rows, cols), 45, std=3.0, device=DEV)
+    w = synth.normal((cols,), 46, std=0.5) + 1
+    xh, rh = x.cpu(), r.cpu()
+    d = ulp_diff_bf16(ops.rmsnorm(x, w.to(DEV), 1e-6).cpu(), orc.rmsnorm_ref(xh, w, 1e-6))
+    assert d.max() <= 1 and (d > 0).float().mean() < 0.02
+    y_ref, r_ref = orc.rmsnorm_ref(xh, w, 1e-6, residual=rh)
+    ops.fused_add_rmsnorm(x, r, w.to(DEV), 1e-6)
+    assert torch.equal(r.cpu(), r_ref)
+    d = ulp_diff_bf16(x.cpu(), y_ref)
+    assert d.max() <= 1 and (d > 0).float().mean() < 0.02
+    wd = synth.normal((128,), 47, std=0.3) + 1
+    for rows, stride in ((163961, 128), (140003, 256), (1048579, 128)):  # dense; 128-wide slices of wider rows; streamed
+        buf = synth.normal((rows, stride), 48, std=1.5, device=DEV)
+        got = ops.rmsnorm(buf[:, :128], wd.to(DEV), 1e-6).cpu()
+        d = ulp_diff_bf16(got, orc.rmsnorm_ref(buf.cpu()[:, :128], wd, 1e-6))
+        assert d.max() <= 1 and (d > 0).float().mean() < 0.02
+
+
+@pytest.mark.parametrize("rows,n", [(4099, 12288), (8193, 12288), (1367, 3072)])
+def test_silu_and_mul_many_rows(rows, n):
+    ops = _ops()
+    synth, _ = _synth()
+    x = synth.normal((rows, 2 * n), 49, std=2.0, device=DEV)
+    d = ulp_diff_bf16(ops.silu_and_mul(x).cpu(), orc.silu_and_mul_ref(x.cpu()))
+    assert d.max() <= 1 and (d > 0).float().mean() < 0.01, (d.max(), (d > 0).float().mean())
+
+
+@pytest.mark.parametrize("T", [7001, 26301])  # runs of four heads per lane group; the larger one streamed
+def test_rope_many_tokens_bit_exact(T):
+    ops = _ops()
+    synth, _ = _synth()
+    D, Hq, Hkv = 128, 32, 8
+    cache = orc.build_cos_sin_cache(D, 40960, 1e6)
+    pos = synth.uniform_int(T, 50, 0, 40960).to(torch.int32)
+    qkv_d = synth.normal((T, (Hq + 2 * Hkv) * D), 51, device=DEV)
+    qkv = qkv_d.cpu()
+    q_ref, k_ref = orc.rope_ref(pos, qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], cache, D)
+    for ref_rounding in (True, False):
+        work = qkv_d.clone()
+        qd, kd = work[:, : Hq * D], work[:, Hq * D: (Hq + Hkv) * D]
+        ops.rope_neox_(pos.to(DEV), qd, kd, cache.to(DEV), D, reference_rounding=ref_rounding)
+        if ref_rounding:
+            assert torch.equal(qd.cpu(), q_ref) and torch.equal(kd.cpu(), k_ref), "reference-rounding RoPE must be bit exact"
+        else:
+            q32, k32 = orc.rope_fp32_ref(pos, qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], cache, D)
+            assert ulp_diff_bf16(qd.cpu(), q32).max() <= 1 and ulp_diff_bf16(kd.cpu(), k32).max() <= 1
+        assert torch.equal(work[:, (Hq + Hkv) * D:], qkv_d[:, (Hq + Hkv) * D:]), "v part must be untouched"
+    # 5 heads per token (not a multiple of the run length): the last run of every token is partial
+    small = synth.normal((T, 5 * D), 52, device=DEV)
+    sh = small.cpu()
+    q_ref, k_ref = orc.rope_ref(pos, sh[:, : 4 * D], sh[:, 4 * D:], cache, D)
+    ops.rope_neox_(pos.to(DEV), small[:, : 4 * D], small[:, 4 * D:], cache.to(DEV), D)
+    assert torch.equal(small[:, : 4 * D].cpu(), q_ref) and torch.equal(small[:, 4 * D:].cpu(), k_ref)
+
+
+def test_store_kv_many_tokens_bit_exact():
+    ops = _ops()
+    synth, _ = _synth()
+    for Hkv, T in ((8, 4101), (1, 33001)):
+        D, slots = 128, T + 300
+        qkv = synth.normal((T, (16 + 2 * Hkv) * D), 53, device=DEV)
+        loc = (synth.permutation(slots - 1, 54)[:T] + 1).to(torch.int32)
+        kvd = torch.zeros((slots, 2, Hkv, D), dtype=torch.bfloat16, device=DEV)
+        ops.store_kv(qkv[:, 16 * D: (16 + Hkv) * D].view(T, Hkv, D), qkv[:, (16 + Hkv) * D:].view(T, Hkv, D), loc.to(DEV), kvd[:, 0], kvd[:, 1])
+        kc, vc = torch.zeros((slots, Hkv, D), dtype=torch.bfloat16), torch.zeros((slots, Hkv, D), dtype=torch.bfloat16)
+        h = qkv.cpu()
+        orc.store_kv_ref(kc, vc, loc, h[:, 16 * D: (16 + Hkv) * D], h[:, (16 + Hkv) * D:])
+        assert torch.equal(kvd[:, 0].cpu(), kc) and torch.equal(kvd[:, 1].cpu(), vc)
+
+
 # ------------------------------------------------------------------------------------------------ batch preparation
 def _prepare_case(bs, ps, seed, max_ctx=512):
     synth, _ = _synth()
