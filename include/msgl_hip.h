@@ -53,6 +53,7 @@ const char* msgl_last_error(void);
  *   MSGL_VARIANT_DECODE_MFMA      0 = gather kernel only, 8 = matrix-core kernel only for 8 heads
  *                                 per kv head, 4 = also for 4 heads per kv head on every shape
  *   MSGL_VARIANT_DECODE_MFMA_WAVES  4 / 8 waves per (request, split) of the matrix-core decode kernel
+ *   MSGL_VARIANT_DECODE_MFMA_DEPTH  2 / 4 tile slots per wave of its four-wave form
  *   MSGL_VARIANT_EXTEND_HEADS     1 / 2 query heads per extend work group
  *   MSGL_VARIANT_EXTEND_WIDE      0 = eight waves (one head each), 1 = four waves (both heads each)
  *   MSGL_VARIANT_EXTEND_RING      2 / 3 slots in the K/V tile ring of the eight-wave extend kernel
@@ -65,7 +66,8 @@ const char* msgl_last_error(void);
 #define MSGL_VARIANT_EXTEND_WIDE 3
 #define MSGL_VARIANT_EXTEND_RING 4
 #define MSGL_VARIANT_EXTEND_KEY_SPLIT 5
-#define MSGL_VARIANT_COUNT 6
+#define MSGL_VARIANT_DECODE_MFMA_DEPTH 6
+#define MSGL_VARIANT_COUNT 7
 int msgl_set_variant(int which, int value);
 int msgl_get_variant(int which);
 

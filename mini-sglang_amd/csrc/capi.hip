@@ -34,7 +34,7 @@ int device_cus() {
     return cached[dev];
 }
 
-static int g_variant[MSGL_VARIANT_COUNT] = {MSGL_VARIANT_AUTO, MSGL_VARIANT_AUTO, MSGL_VARIANT_AUTO,
+static int g_variant[MSGL_VARIANT_COUNT] = {MSGL_VARIANT_AUTO, MSGL_VARIANT_AUTO, MSGL_VARIANT_AUTO, MSGL_VARIANT_AUTO,
                                             MSGL_VARIANT_AUTO, MSGL_VARIANT_AUTO, MSGL_VARIANT_AUTO};
 int variant(int which) { return __atomic_load_n(&g_variant[which], __ATOMIC_RELAXED); }
 

@@ -57,34 +57,43 @@ __device__ __forceinline__ SplitInfo split_info(const DecodeParams& p, int b, in
 
 // End of a (request, split) work group of either decode kernel: every wave has left its state for its kv head in LDS
 // (lds_o [wave][G][128] unnormalised outputs, lds_ml [wave][G][2] running max in log2 units and running sum) and the
-// group has passed a barrier.  The calling wave, the first of the WPH waves of kv head h, merges them and writes either
-// the final bf16 output (the request has this one split and no partials from another kernel) or the split's partial.
+// group has passed a barrier.  The WPH waves of kv head h (sub = 0 .. WPH - 1, all of them call this) share the merge,
+// four output columns per lane and pass, and write either the final bf16 output (the request has this one split and no
+// partials from another kernel) or the split's partial.
 template <int G, int WPH>
-__device__ __forceinline__ void merge_waves_and_store(const DecodeParams& p, const float* lds_o, const float* lds_ml, int h, int lane, int b,
-                                                      int split, bool final_out) {
+__device__ __forceinline__ void merge_waves_and_store(const DecodeParams& p, const float* lds_o, const float* lds_ml, int h, int sub, int lane,
+                                                      int b, int split, bool final_out) {
 #pragma unroll
-    for (int idx = lane * 2; idx < G * kD; idx += 128) {
+    for (int idx = (sub * 64 + lane) * 4; idx < G * kD; idx += WPH * 256) {
         const int g = idx / kD, d = idx - g * kD;
+        float mw[WPH], lw[WPH];
+        float4 ow[WPH];
+#pragma unroll
+        for (int w = 0; w < WPH; ++w) {  // every read issued before the first is used
+            const int ww = h * WPH + w;
+            const float2 ml = *reinterpret_cast<const float2*>(lds_ml + (ww * G + g) * 2);
+            mw[w] = ml.x, lw[w] = ml.y;
+            ow[w] = *reinterpret_cast<const float4*>(lds_o + (ww * G + g) * kD + d);
+        }
         float M = kNegBig;
 #pragma unroll
-        for (int w = 0; w < WPH; ++w) M = fmaxf(M, lds_ml[((h * WPH + w) * G + g) * 2]);
-        float L = 0.f, o0 = 0.f, o1 = 0.f;
+        for (int w = 0; w < WPH; ++w) M = fmaxf(M, mw[w]);
+        float L = 0.f;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int w = 0; w < WPH; ++w) {
-            const int ww = h * WPH + w;
-            const float f = fast_exp2(lds_ml[(ww * G + g) * 2] - M);
-            L += f * lds_ml[(ww * G + g) * 2 + 1];
-            const float2 o = *reinterpret_cast<const float2*>(lds_o + (ww * G + g) * kD + d);
-            o0 += f * o.x;
-            o1 += f * o.y;
+            const float f = fast_exp2(mw[w] - M);
+            L += f * lw[w];
+            o.x += f * ow[w].x, o.y += f * ow[w].y, o.z += f * ow[w].z, o.w += f * ow[w].w;
         }
         const int hq = h * G + g;
         if (final_out) {
             const float inv = 1.0f / L;
-            *reinterpret_cast<uint32_t*>(p.out + (int64_t)b * p.out_stride + hq * kD + d) = pack_bf16(o0 * inv, o1 * inv);
+            *reinterpret_cast<uint2*>(p.out + (int64_t)b * p.out_stride + hq * kD + d) =
+                make_uint2(pack_bf16(o.x * inv, o.y * inv), pack_bf16(o.z * inv, o.w * inv));
         } else {
             const int64_t row = ((int64_t)b * p.max_splits + split) * p.Hq + hq;
-            *reinterpret_cast<float2*>(p.ws_o + row * kD + d) = make_float2(o0, o1);
+            *reinterpret_cast<float4*>(p.ws_o + row * kD + d) = o;
             if (d == 0) *reinterpret_cast<float2*>(p.ws_ml + row * 2) = make_float2(M, L);
         }
     }

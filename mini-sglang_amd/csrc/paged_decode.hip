@@ -70,7 +70,11 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
     const int split = item / p.bs;
     const int b = item - split * p.bs;
     const int chunk = split_chunk(p);
+    // (the request's table row is asked for together with its lengths, ahead of the early exit below: one round trip
+    // to memory less in front of the first page-table read)
+    const int req_row = p.req_idx[b];
     const SplitInfo si = split_info(p, b, chunk);
+    asm volatile("" ::"s"(req_row));
     const int S = si.S, nsplit = si.nsplit;
     if (split >= nsplit) return;
     const int t0 = si.start + split * chunk;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
     // this wave's tiles are sub, sub + WPH, ...; "n" below counts them
     const int my_tiles = (ntiles > sub) ? (ntiles - sub + WPH - 1) / WPH : 0;
 
-    const int32_t* r2t_row = p.r2t + (int64_t)p.req_idx[b] * p.r2t_stride;
+    const int32_t* r2t_row = p.r2t + (int64_t)req_row * p.r2t_stride;
     const uint16_t* kbase = p.kc + h * kD + s8 * 8;
     const uint16_t* vbase = p.vc + h * kD + c * 8;
 
@@ -362,9 +366,7 @@ __global__ __launch_bounds__(kWaves * 64) void paged_decode_kernel(DecodeParams 
         }
     }
     __syncthreads();
-    if (sub != 0) return;
-
-    merge_waves_and_store<G, WPH>(p, lds_o, lds_ml, h, lane, b, split, nsplit == 1 && si.extra == 0);
+    merge_waves_and_store<G, WPH>(p, lds_o, lds_ml, h, sub, lane, b, split, nsplit == 1 && si.extra == 0);
 }
 
 // Launch order for a ragged decode batch: item = split * bs + request, cost = its number of 16-token tiles.
@@ -392,91 +394,105 @@ __global__ __launch_bounds__(kPlanThreads) void decode_plan_kernel(DecodeParams 
     plan_sort_descending(p.bs * p.max_splits, tiles, plan, bins, part);
 }
 
-// Merge the split-K partials of one (request, query head).  NW waves take every NW-th split, lane l owns
-// output columns 2l and 2l+1; each thread reads the (max, sum) pairs of its splits once, the split weights
-// are formed in parallel and kept in LDS, so the per-split work is one 8-byte load and two FMAs, four
-// splits in flight per wave.
-constexpr int kMergeMaxSplits = 4096;
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void paged_decode_merge_kernel(DecodeParams p) {
-    constexpr int NT = NW * 64;
-    constexpr int PER = (kMergeMaxSplits + NT - 1) / NT;  // (max, sum) pairs a thread may own
-    __shared__ float red[NW];
-    __shared__ float wts[kMergeMaxSplits];
-    __shared__ float part[NW][kD];
-    const int b = blockIdx.x / p.Hq;
-    const int hq = blockIdx.x - b * p.Hq;
+// Merge the split-K partials of one (request, query head) when there are many of them (long contexts at small batch:
+// few rows, up to thousands of splits).  DQ work groups share a row, each owning 128 / DQ output columns, so that even
+// one request covers dozens of compute units; inside a group LPR lanes hold a split's columns (16 bytes each) and the
+// 256 / LPR lane rows take every (256 / LPR)-th split, four splits per lane in flight.  One pass: every lane folds its
+// splits with a running maximum of its own (online softmax over the partials: no first pass for the global maximum,
+// so the (max, sum) pairs and the outputs are all requested together), then the lane rows are folded by shuffles and
+// the four waves through LDS.
+template <int DQ>
+__global__ __launch_bounds__(256) void paged_decode_merge_kernel(DecodeParams p) {
+    constexpr int COLS = kD / DQ;        // columns of this work group
+    constexpr int LPR = COLS / 4;        // lanes per split
+    constexpr int ROWS = 256 / LPR;      // splits per pass
+    constexpr int UNR = 4;
+    static_assert(LPR >= 1 && LPR <= 64 && (LPR & (LPR - 1)) == 0, "lanes per split");
+    __shared__ float sh[4][LPR][6];
+    const int dq = blockIdx.x % DQ;
+    const int row = blockIdx.x / DQ;
+    const int b = row / p.Hq;
+    const int hq = row - b * p.Hq;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = tid % LPR, r = tid / LPR;
+    const int64_t row0 = ((int64_t)b * p.max_splits) * p.Hq + hq;
+    const float* src_o = p.ws_o + row0 * kD + dq * COLS + c * 4;
+    const float* src_ml = p.ws_ml + row0 * 2;
+    const int64_t step = (int64_t)p.Hq * kD, step_ml = (int64_t)p.Hq * 2;
+    // The first ROWS * UNR slots are requested before the number of splits is known (it hangs on a load of the request's
+    // length: one round trip to memory saved); every slot index below max_splits is inside the workspace, and what
+    // an unused slot holds is discarded below.
+    float4 o[UNR];
+    float2 ml[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const int s = min(r + u * ROWS, p.max_splits - 1);
+        ml[u] = *reinterpret_cast<const float2*>(src_ml + (int64_t)s * step_ml);
+        o[u] = *reinterpret_cast<const float4*>(src_o + (int64_t)s * step);
+    }
     const SplitInfo si = split_info(p, b, split_chunk(p));
     const int nsplit = min(si.nsplit + si.extra, p.max_splits);  // this kernel's partials, then the shared-prefix kernel's
     if (nsplit <= 1 && si.extra == 0) return;  // written directly by the main kernel
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t row0 = ((int64_t)b * p.max_splits) * p.Hq + hq;
-    // running max over splits
-    float2 ml[PER];
-    float M = kNegBig;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float m = kNegBig, l = 0.f;
+    for (int s0 = r; s0 < nsplit; s0 += ROWS * UNR) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int s = tid + i * NT;
-        ml[i] = s < nsplit ? *reinterpret_cast<const float2*>(p.ws_ml + (row0 + (int64_t)s * p.Hq) * 2) : make_float2(kNegBig, 0.f);
-        M = fmaxf(M, ml[i].x);
-    }
+        for (int u = 0; u < UNR; ++u) {
+            const int s = s0 + u * ROWS;
+            const bool live = s < nsplit;
+            if (s0 != r) {  // (the first pass has its values already)
+                ml[u] = live ? *reinterpret_cast<const float2*>(src_ml + (int64_t)s * step_ml) : make_float2(kNegBig, 0.f);
+                o[u] = live ? *reinterpret_cast<const float4*>(src_o + (int64_t)s * step) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (!live) {
+                ml[u] = make_float2(kNegBig, 0.f);
+                o[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        float mn = m;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off));
-    if (lane == 0) red[wave] = M;
-    __syncthreads();
-    M = red[0];
+        for (int u = 0; u < UNR; ++u) mn = fmaxf(mn, ml[u].x);
+        const float a = fast_exp2(m - mn);
+        acc.x *= a, acc.y *= a, acc.z *= a, acc.w *= a;
+        l *= a;
+        m = mn;
 #pragma unroll
-    for (int w = 1; w < NW; ++w) M = fmaxf(M, red[w]);
-    __syncthreads();
-    // split weights and the normaliser
-    float L = 0.f;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int s = tid + i * NT;
-        if (s < nsplit) {
-            const float f = fast_exp2(ml[i].x - M);
-            wts[s] = f;
-            L += f * ml[i].y;
+        for (int u = 0; u < UNR; ++u) {
+            const float w = fast_exp2(ml[u].x - mn);
+            acc.x = fmaf(w, o[u].x, acc.x), acc.y = fmaf(w, o[u].y, acc.y);
+            acc.z = fmaf(w, o[u].z, acc.z), acc.w = fmaf(w, o[u].w, acc.w);
+            l = fmaf(w, ml[u].y, l);
         }
     }
-    L = wave_sum(L);
-    if (lane == 0) red[wave] = L;
-    __syncthreads();
-    L = red[0];
+    // fold two partial results (a: this lane's, b: the other's); both maxima at kNegBig (rows past the last split) give
+    // weights of one on zero sums
+    auto fold = [&](float mo, float lo, const float4& ao) {
+        const float mn = fmaxf(m, mo);
+        const float wa = fast_exp2(m - mn), wb = fast_exp2(mo - mn);
+        acc.x = acc.x * wa + ao.x * wb, acc.y = acc.y * wa + ao.y * wb;
+        acc.z = acc.z * wa + ao.z * wb, acc.w = acc.w * wa + ao.w * wb;
+        l = l * wa + lo * wb;
+        m = mn;
+    };
 #pragma unroll
-    for (int w = 1; w < NW; ++w) L += red[w];
-    // weighted sum of the partial outputs
-    const int d = lane * 2;
-    const float* src = p.ws_o + row0 * kD + d;
-    const int64_t step = (int64_t)p.Hq * kD;
-    float o0 = 0.f, o1 = 0.f;
-    int s = wave;
-    for (; s + 3 * NW < nsplit; s += 4 * NW) {
-        const float2 a0 = *reinterpret_cast<const float2*>(src + (int64_t)s * step);
-        const float2 a1 = *reinterpret_cast<const float2*>(src + (int64_t)(s + NW) * step);
-        const float2 a2 = *reinterpret_cast<const float2*>(src + (int64_t)(s + 2 * NW) * step);
-        const float2 a3 = *reinterpret_cast<const float2*>(src + (int64_t)(s + 3 * NW) * step);
-        const float f0 = wts[s], f1 = wts[s + NW], f2 = wts[s + 2 * NW], f3 = wts[s + 3 * NW];
-        o0 = fmaf(f0, a0.x, o0), o1 = fmaf(f0, a0.y, o1);
-        o0 = fmaf(f1, a1.x, o0), o1 = fmaf(f1, a1.y, o1);
-        o0 = fmaf(f2, a2.x, o0), o1 = fmaf(f2, a2.y, o1);
-        o0 = fmaf(f3, a3.x, o0), o1 = fmaf(f3, a3.y, o1);
+    for (int off = LPR; off < 64; off <<= 1) {
+        const float mo = __shfl_xor(m, off), lo = __shfl_xor(l, off);
+        const float4 ao = make_float4(__shfl_xor(acc.x, off), __shfl_xor(acc.y, off), __shfl_xor(acc.z, off), __shfl_xor(acc.w, off));
+        fold(mo, lo, ao);
     }
-    for (; s < nsplit; s += NW) {
-        const float2 o = *reinterpret_cast<const float2*>(src + (int64_t)s * step);
-        const float f = wts[s];
-        o0 = fmaf(f, o.x, o0);
-        o1 = fmaf(f, o.y, o1);
+    if (lane < LPR) {
+        float* d = sh[wave][lane];
+        d[0] = acc.x, d[1] = acc.y, d[2] = acc.z, d[3] = acc.w, d[4] = m, d[5] = l;
     }
-    part[wave][d] = o0;
-    part[wave][d + 1] = o1;
     __syncthreads();
-    if (wave == 0) {
-        o0 = part[0][d], o1 = part[0][d + 1];
+    if (tid < LPR) {
 #pragma unroll
-        for (int w = 1; w < NW; ++w) o0 += part[w][d], o1 += part[w][d + 1];
-        const float inv = 1.0f / L;
-        *reinterpret_cast<uint32_t*>(p.out + (int64_t)b * p.out_stride + hq * kD + d) = pack_bf16(o0 * inv, o1 * inv);
+        for (int w = 1; w < 4; ++w) {
+            const float* d = sh[w][tid];
+            fold(d[4], d[5], make_float4(d[0], d[1], d[2], d[3]));
+        }
+        const float inv = 1.0f / l;
+        *reinterpret_cast<uint2*>(p.out + (int64_t)b * p.out_stride + hq * kD + dq * COLS + tid * 4) =
+            make_uint2(pack_bf16(acc.x * inv, acc.y * inv), pack_bf16(acc.z * inv, acc.w * inv));
     }
 }
 
@@ -550,7 +566,7 @@ static int launch_decode(const DecodeParams& p, int page_size, hipStream_t strea
         if (p.max_splits <= 16)  // few splits: a wave per row, four rows per group
             hipLaunchKernelGGL(paged_decode_merge_small_kernel, dim3((p.bs * p.Hq + 3) / 4), dim3(256), 0, stream, p);
         else
-            hipLaunchKernelGGL(paged_decode_merge_kernel<16>, dim3(p.bs * p.Hq), dim3(1024), 0, stream, p);
+            hipLaunchKernelGGL(paged_decode_merge_kernel<8>, dim3(p.bs * p.Hq * 8), dim3(256), 0, stream, p);
         rc = check_launch("paged_decode_merge_kernel");
     }
     return rc;
@@ -599,8 +615,8 @@ static int paged_decode_checked(const void* q, int64_t q_stride, const void* k_c
                  "msgl_paged_decode: null pointer argument");
     MSGL_REQUIRE(aligned16(q) && aligned16(k_cache) && aligned16(v_cache) && aligned16(out),
                  "msgl_paged_decode: q, k_cache, v_cache and out must be 16-byte aligned");
-    MSGL_REQUIRE(q_stride % 8 == 0 && cache_stride % 8 == 0 && out_stride % 2 == 0,
-                 "msgl_paged_decode: strides must keep 16-byte row alignment");
+    MSGL_REQUIRE(q_stride % 8 == 0 && cache_stride % 8 == 0 && out_stride % 4 == 0,
+                 "msgl_paged_decode: strides must keep 16-byte (q, cache) / 8-byte (out) row alignment");
     MSGL_REQUIRE(q_stride >= (int64_t)Hq * D && out_stride >= (int64_t)Hq * D && cache_stride >= (int64_t)Hkv * D,
                  "msgl_paged_decode: stride smaller than a row");
     const size_t need = msgl_paged_decode_workspace_bytes(bs, Hq, D, max_splits);

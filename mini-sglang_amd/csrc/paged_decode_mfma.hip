@@ -8,9 +8,10 @@
 // (O^T += V^T.P^T); the matrix pipe is then busy a few percent of the time and the kernel is paced by its loads.
 //
 //   * K and V rows go from HBM straight into LDS (global_load_lds_dwordx4: no staging registers, no ds_write),
-//     into a ring of two 8 KiB tile slots PER WAVE: tiles are private to a wave, so the loop has no barrier, only
-//     counted s_waitcnt vmcnt.  One instruction moves 4 rows of 256 B; K(n+2) is issued as soon as the K fragments
-//     of tile n are in registers, V(n+2) likewise, so each wave keeps about two tiles (16 KiB) in flight.
+//     into a ring of DEP 8 KiB tile slots PER WAVE: tiles are private to a wave, so the loop has no barrier, only
+//     counted s_waitcnt vmcnt.  One instruction moves 4 rows of 256 B; K(n+DEP) is issued as soon as the K fragments
+//     of tile n are in registers, V(n+DEP) likewise, so each wave keeps about DEP tiles in flight: 16 KiB with the
+//     two slots of the eight-wave groups, 32 KiB with the four slots of the four-wave groups (128 KiB per CU either way).
 //   * The LDS destination of such a load is lane-linear, the source address is per lane: the XOR swizzles that make
 //     the fragment reads conflict free are applied to the SOURCE (lane p of a row fetches chunk p ^ f(row)).
 //       K rows are read as MFMA A operands with ds_read_b128 (row = token, 16-byte chunk = 8 dims): f(row) = row;
@@ -31,10 +32,21 @@ typedef __attribute__((ext_vector_type(8))) __bf16 mbf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short mshort4_t;
 typedef __attribute__((ext_vector_type(4))) float mf32x4_t;
 
-constexpr int kMKSlots = 2;             // K tiles (16 rows of 256 B = 4 KiB) a wave holds: one being read, the others on their way
-constexpr int kMVSlots = 2;             // V tiles
-constexpr int kMHalf = 4096;            // bytes of a K or V tile
-constexpr int kMWaveBytes = (kMKSlots + kMVSlots) * kMHalf;   // (three K slots, 20 KiB a wave, measured 3-5 % slower than two)
+// Diagnostic builds only (-DDEC_STAMPS, scripts/stamp_decode.sh): wave 0 of every work group leaves the value of the
+// chip-wide 100 MHz counter at six points of its life; tools/decode_bench prints where a launch's time goes.
+#ifdef DEC_STAMPS
+__device__ unsigned long long g_dec_stamps[8192][6];
+#define DSTAMP(i)                                                                                       \
+    do {                                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_dec_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define DSTAMP(i)
+#endif
+
+constexpr int kMHalf = 4096;            // bytes of a K or V tile (16 rows of 256 B)
+// A wave's ring: DEP K tiles, then DEP V tiles (one of each being read, the others on their way).
+constexpr int wave_ring_bytes(int dep) { return 2 * dep * kMHalf; }
 
 // Four LDS-DMA loads of 4 rows x 256 B each into 4 KiB at LDS byte address `dst`; lane offsets off[i] (bytes from
 // `base`) select the row and the swizzled chunk.  The statement first waits for the wave's outstanding LDS reads (the
@@ -75,7 +87,9 @@ __device__ __forceinline__ void wait_dma_groups(int groups) {
         case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
         case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
     }
 }
 
@@ -95,9 +109,12 @@ __device__ __forceinline__ float max_over_lane_groups(float x) {
 
 // G = query heads per kv head (any count up to 16 fits the 16 padded columns; built for 8 and, for ranks with one or two
 // kv heads, 4), HPB = local kv heads.
-template <int G, int HPB, int NW = kWaves>
+template <int G, int HPB, int NW = kWaves, int DEP = 2>
 __global__ __launch_bounds__(NW * 64) void paged_decode_mfma_kernel(DecodeParams p) {
     static_assert(G <= 16, "the query heads of a kv head are the 16 columns of S^T");
+    static_assert(DEP >= 2 && DEP <= 4, "at most 2 * DEP - 1 = 7 load groups outstanding (wait_dma_groups)");
+    constexpr int kMWaveBytes = wave_ring_bytes(DEP);
+    DSTAMP(0);
     constexpr int WPH = NW / HPB;  // waves sharing one kv head
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -109,7 +126,11 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_mfma_kernel(DecodeParams
     const int split = item / p.bs;
     const int b = item - split * p.bs;
     const int chunk = split_chunk(p);
+    // (the request's table row is asked for together with its lengths, ahead of the early exit below: one round trip
+    // to memory less in front of the first page-table read)
+    const int req_row = p.req_idx[b];
     const SplitInfo si = split_info(p, b, chunk);
+    asm volatile("" ::"s"(req_row));
     const int S = si.S, nsplit = si.nsplit;
     if (split >= nsplit) return;
     const int t0 = si.start + split * chunk;  // a multiple of 16: tiles never straddle a 16-slot run
@@ -124,21 +145,23 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_mfma_kernel(DecodeParams
     const int sub = wave - h * WPH;
     const int my_tiles = (ntiles > sub) ? (ntiles - sub + WPH - 1) / WPH : 0;  // own tiles: sub, sub + WPH, ...
 
-    const int32_t* r2t_row = p.r2t + (int64_t)p.req_idx[b] * p.r2t_stride;
+    const int32_t* r2t_row = p.r2t + (int64_t)req_row * p.r2t_stride;
     // LDS byte address of this wave's ring (what M0 takes)
     const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)wave * kMWaveBytes;
-    const char* ring_ptr = smem + wave * kMWaveBytes;  // [kMKSlots K tiles][kMVSlots V tiles]
+    const char* ring_ptr = smem + wave * kMWaveBytes;  // [DEP K tiles][DEP V tiles]
 
-    // Q^T fragments (B operand of S^T = K.Q^T): lane (head qn, group g4) holds dims 32 ks + 8 g4 .. + 8
-    uint4 qf[4];
+    // Q^T fragments (B operand of S^T = K.Q^T): lane (head qn, group g4) holds dims 32 ks + 8 g4 .. + 8.  Loaded by
+    // statements the compiler does not count, ahead of the first LDS-DMA loads and without waiting for them there:
+    // vector loads return in issue order, so once the first K tile has landed (the counted wait in front of the loop) so
+    // has the query; a load the compiler counts would cost a round trip to memory before the first K/V load, or a full
+    // vmcnt(0) inside the loop.  Padding heads (qn >= G) read head 0's row: their columns are never stored.
+    typedef __attribute__((ext_vector_type(4))) unsigned int mu32x4_t;
+    mu32x4_t qraw[4];
+    {
+        const uint16_t* qp = p.q + (int64_t)b * p.q_stride + (h * G + (qn < G ? qn : 0)) * kD + g4 * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-        qf[ks] = qn < G ? *reinterpret_cast<const uint4*>(p.q + (int64_t)b * p.q_stride + (h * G + qn) * kD + ks * 32 + g4 * 8) : make_uint4(0, 0, 0, 0);
-
-    // the query is in registers before the first LDS-DMA load is issued: a use the compiler sees, so that it waits for
-    // these loads here and not, with a full vmcnt(0), at their first use inside the tile loop
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[ks].x), "v"(qf[ks].y), "v"(qf[ks].z), "v"(qf[ks].w));
+        for (int ks = 0; ks < 4; ++ks) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qraw[ks]) : "v"(qp + ks * 32) : "memory");
+    }
 
     // source offsets of the LDS-DMA loads: instruction i brings rows 4 i + g4 of the tile; position qn of row r gets chunk
     // qn ^ r (K) or qn ^ 2 (r & 7) (V).  Bytes from the tile's first row of this kv head.
@@ -181,51 +204,54 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_mfma_kernel(DecodeParams
     auto table_wait = [&](int& idx) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(idx)::"memory"); };
     auto issue_k = [&](int n, int idx) {
         const uint16_t* kb = p.kc + ((int64_t)idx * p.cache_stride + h * kD);
-        const uint32_t dst = ring + (uint32_t)(n % kMKSlots) * kMHalf;
+        const uint32_t dst = ring + (uint32_t)(n % DEP) * kMHalf;
         if (t0 + (sub + n * WPH) * kTile >= reuse_len) dma_rows16<true>(kb, dst, koff);
         else dma_rows16<false>(kb, dst, koff);
     };
     auto issue_v = [&](int n, int idx) {
         const uint16_t* vb = p.vc + ((int64_t)idx * p.cache_stride + h * kD);
-        const uint32_t dst = ring + (uint32_t)(kMKSlots + (n & 1)) * kMHalf;
+        const uint32_t dst = ring + (uint32_t)(DEP + n % DEP) * kMHalf;
         if (t0 + (sub + n * WPH) * kTile >= reuse_len) dma_rows16<true>(vb, dst, voff);
         else dma_rows16<false>(vb, dst, voff);
     };
-    // Issue order of the wave's load groups (4 loads each): K0 V0 K1 V1 (K2 with three K slots) up front, then tile i issues
-    // K(i + KA), KA = kMKSlots, once its K fragments are in registers and V(i+2) once its V fragments are.  Loads complete in that order, so "K(n) has
-    // landed" is "at most (groups issued so far - 1 - position of K(n)) groups outstanding".
+    // Issue order of the wave's load groups (4 loads each): K0 V0 .. K(DEP-1) V(DEP-1) up front, then tile n issues
+    // K(n+DEP) once its K fragments are in registers and V(n+DEP) once its V fragments are: the sequence is K0 V0 K1 V1
+    // ... whatever T is, K(j) at position 2 j and V(j) at 2 j + 1.  Loads complete in that order, so "group at position
+    // x has landed" is "at most (groups issued so far - 1 - x) groups outstanding".  When tile n starts, every group of
+    // the tiles below min(T, n + DEP) has been issued.
     const int T = my_tiles;
-    constexpr int KA = kMKSlots;
-    static_assert(KA == 2 || KA == 3, "K tiles in flight");
-    const int up_front = (T >= 1 ? 2 : 0) + (T >= 2 ? 2 : 0) + (KA == 3 && T >= 3 ? 1 : 0);
-    auto issued_before_tile = [&](int i) { return up_front + min(i, max(0, T - KA)) + min(i, max(0, T - 2)); };
-    auto pos_k = [&](int j) { return j < KA ? 2 * j : issued_before_tile(j - KA); };
-    auto pos_v = [&](int j) { return j < 2 ? 2 * j + 1 : issued_before_tile(j - 2) + ((j - 2 + KA < T) ? 1 : 0); };
-
     if (T > 0) {
-        int ia = table_load(0), ib = table_load(1), ic = table_load(2);
-        table_wait(ia), table_wait(ib), table_wait(ic);
-        issue_k(0, ia);
-        issue_v(0, ia);
-        if (T > 1) issue_k(1, ib), issue_v(1, ib);
-        if (KA == 3 && T > 2) issue_k(2, ic);
-        // table entries at hand while tile n is worked on: of tile n + 2 (for its V) and of tile n + KA (for its K)
-        int idx_v = ic, idx_k = ic;
-        if (KA == 3) {
-            idx_k = table_load(3);
-            table_wait(idx_k);
+        int first[DEP];
+#pragma unroll
+        for (int j = 0; j < DEP; ++j) first[j] = table_load(j);
+        int idx_ahead = table_load(DEP);  // entry of tile n + DEP while tile n is worked on
+#pragma unroll
+        for (int j = 0; j < DEP; ++j) table_wait(first[j]);
+        table_wait(idx_ahead);
+        DSTAMP(1);
+#pragma unroll
+        for (int j = 0; j < DEP; ++j)
+            if (j < T) issue_k(j, first[j]), issue_v(j, first[j]);
+        // K(0) has landed: so has the query (see above); from here on the compiler may use it
+        wait_dma_groups(2 * min(T, DEP) - 1);
+        DSTAMP(2);
+        uint4 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            asm volatile("" : "+v"(qraw[ks]));
+            qf[ks] = make_uint4(qraw[ks].x, qraw[ks].y, qraw[ks].z, qraw[ks].w);
         }
         for (int n = 0; n < T; ++n) {
-            const char* kslot = ring_ptr + (n % kMKSlots) * kMHalf;
-            const char* vslot = ring_ptr + (kMKSlots + (n & 1)) * kMHalf;
-            const int before = issued_before_tile(n);
-            const bool more_k = n + KA < T, more_v = n + 2 < T;
-            wait_dma_groups(before - 1 - pos_k(n));
+            const char* kslot = ring_ptr + (n % DEP) * kMHalf;
+            const char* vslot = ring_ptr + (DEP + n % DEP) * kMHalf;
+            const int issued = 2 * min(T, n + DEP);
+            const bool more = n + DEP < T;
+            wait_dma_groups(issued - 1 - 2 * n);
             uint4 kf[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(kslot + kread[ks]);
-            if (more_k) issue_k(n + KA, idx_k);  // (waits for the four reads above first)
-            int idx_after = table_load(n + KA + 1);  // used by the next iteration; waited for at the end of this one
+            if (more) issue_k(n + DEP, idx_ahead);  // (waits for the four reads above first)
+            int idx_after = table_load(n + DEP + 1);  // used by the next iteration; waited for at the end of this one
             mf32x4_t s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
@@ -252,20 +278,20 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_mfma_kernel(DecodeParams
             // P^T as the B operand of O^T += V^T.P^T: k = tokens 4 g4 + j, n = head qn
             const uint2 pp = make_uint2(pack_bf16(pr[0], pr[1]), pack_bf16(pr[2], pr[3]));
             const mshort4_t pfrag = __builtin_bit_cast(mshort4_t, pp);
-            wait_dma_groups(before + (more_k ? 1 : 0) - 1 - pos_v(n));
+            wait_dma_groups(issued + (more ? 1 : 0) - 1 - (2 * n + 1));
             mshort4_t vf[8];
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb)
                 vf[mb] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) mshort4_t*)(vslot + vread[mb]));
-            if (more_v) issue_v(n + 2, idx_v);
+            if (more) issue_v(n + DEP, idx_ahead);
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb) o[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[mb], pfrag, o[mb], 0, 0, 0);
             table_wait(idx_after);
-            idx_v = KA == 3 ? idx_k : idx_after;
-            idx_k = idx_after;
+            idx_ahead = idx_after;
         }
     }
 
+    DSTAMP(3);
     // this lane's head: total of the four lane groups' sums
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
@@ -285,22 +311,23 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_mfma_kernel(DecodeParams
         }
     }
     __syncthreads();
-    if (sub != 0) return;
-    merge_waves_and_store<G, WPH>(p, lds_o, lds_ml, h, lane, b, split, nsplit == 1 && si.extra == 0);
+    DSTAMP(4);
+    merge_waves_and_store<G, WPH>(p, lds_o, lds_ml, h, sub, lane, b, split, nsplit == 1 && si.extra == 0);
+    DSTAMP(5);
 }
 
-template <int G, int HPB, int NW = kWaves>
+template <int G, int HPB, int NW = kWaves, int DEP = 2>
 static int launch_mfma(const DecodeParams& p, hipStream_t stream) {
-    constexpr int kLds = NW * kMWaveBytes;
+    constexpr int kLds = NW * wave_ring_bytes(DEP);
     static PerDeviceOnce once;  // the rings need more than the 64 KiB a kernel gets by default
     if (!once.ensure([] {
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(paged_decode_mfma_kernel<G, HPB, NW>),
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(paged_decode_mfma_kernel<G, HPB, NW, DEP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
         })) {
         set_error("msgl_paged_decode: cannot reserve %d bytes of LDS", kLds);
         return MSGL_E_LAUNCH;
     }
-    hipLaunchKernelGGL((paged_decode_mfma_kernel<G, HPB, NW>), dim3(p.bs * p.max_splits), dim3(NW * 64), kLds, stream, p);
+    hipLaunchKernelGGL((paged_decode_mfma_kernel<G, HPB, NW, DEP>), dim3(p.bs * p.max_splits), dim3(NW * 64), kLds, stream, p);
     return check_launch("paged_decode_mfma_kernel");
 }
 
@@ -318,8 +345,15 @@ int launch_decode_mfma(const DecodeParams& p, int G, int Hkv, hipStream_t stream
                 const int forced = variant(MSGL_VARIANT_DECODE_MFMA_WAVES);
                 const int64_t grid = (int64_t)p.bs * p.max_splits, cus = device_cus();
                 const bool four = forced > 0 ? forced == 4 : grid <= (Hkv == 1 ? 2 * cus : cus);
-                if (Hkv == 1) return four ? launch_mfma<8, 1, 4>(p, stream) : launch_mfma<8, 1>(p, stream);
-                return four ? launch_mfma<8, 2, 4>(p, stream) : launch_mfma<8, 2>(p, stream);
+                // Four tile slots per wave instead of two (the whole 128 KiB of a CU's ring space in flight from one group)
+                // for launches of at most one four-wave group per CU whose waves have at least 16 tiles each: measured
+                // 3 % ahead at 8 requests x 131072 tokens in 32 splits; with 8 tiles per wave (one request in 256 splits)
+                // the deeper start-up burst delays the first tile by 2 us and the launch ends 1.5 us later.  A split size
+                // only known on the device (captured launches) takes two slots.
+                const int depth = variant(MSGL_VARIANT_DECODE_MFMA_DEPTH);
+                const bool deep = four && (depth > 0 ? depth == 4 : (grid <= cus && p.chunk_dev == nullptr && p.chunk >= 16 * kTile * (4 / Hkv)));
+                if (Hkv == 1) return deep ? launch_mfma<8, 1, 4, 4>(p, stream) : four ? launch_mfma<8, 1, 4>(p, stream) : launch_mfma<8, 1>(p, stream);
+                return deep ? launch_mfma<8, 2, 4, 4>(p, stream) : four ? launch_mfma<8, 2, 4>(p, stream) : launch_mfma<8, 2>(p, stream);
             }
             case 4: return launch_mfma<8, 4>(p, stream);
             case 8: return launch_mfma<8, 8>(p, stream);
@@ -339,3 +373,9 @@ int launch_decode_mfma(const DecodeParams& p, int G, int Hkv, hipStream_t stream
 }
 
 }  // namespace msgl
+
+#ifdef DEC_STAMPS
+extern "C" void msgl_decode_stamps(unsigned long long* out, int groups) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(msgl::g_dec_stamps), sizeof(unsigned long long) * 6 * (groups < 8192 ? groups : 8192));
+}
+#endif

@@ -18,7 +18,8 @@ DECODE_TILE = 16  # tokens per wave iteration of the decode kernel; split chunks
 
 # msgl_set_variant's choices (include/msgl_hip.h): tests and measurements pin a kernel form with them; the library
 # itself never reads its environment and a serving process leaves them all on "auto" (-1)
-VARIANTS = {"decode_mfma": 0, "decode_mfma_waves": 1, "extend_heads": 2, "extend_wide": 3, "extend_ring": 4, "extend_key_split": 5}
+VARIANTS = {"decode_mfma": 0, "decode_mfma_waves": 1, "extend_heads": 2, "extend_wide": 3, "extend_ring": 4, "extend_key_split": 5,
+            "decode_mfma_depth": 6}
 
 
 def set_variant(name: str, value: Optional[int]) -> int:

@@ -17,6 +17,9 @@
 #include <vector>
 
 #include "../include/msgl_hip.h"
+#ifdef DEC_STAMPS
+extern "C" void msgl_decode_stamps(unsigned long long* out, int groups);
+#endif
 
 #define CK(x)                                                                                  \
     do {                                                                                       \
@@ -57,6 +60,10 @@ int main(int argc, char** argv) {
         else if (a == "--splits") splits = v;
         else if (a == "--interleaved") interleaved = v;
         else if (a == "--stream") kv_stream = v;
+        // kernel-form overrides (msgl_set_variant): what the library would otherwise choose from the shape
+        else if (a == "--mfma") msgl_set_variant(MSGL_VARIANT_DECODE_MFMA, v);
+        else if (a == "--waves") msgl_set_variant(MSGL_VARIANT_DECODE_MFMA_WAVES, v);
+        else if (a == "--depth") msgl_set_variant(MSGL_VARIANT_DECODE_MFMA_DEPTH, v);
         else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
     }
     const int D = 128;
@@ -142,5 +149,28 @@ int main(int argc, char** argv) {
     printf("{\"bs\": %d, \"ctx\": %d, \"ps\": %d, \"hq\": %d, \"hkv\": %d, \"chunk\": %d, \"splits\": %d, \"interleaved\": %d, "
            "\"ms_per_step\": %.4f, \"GBps\": %.1f, \"bytes_per_step\": %.0f}\n",
            bs, ctx, ps, hq, hkv, chunk, splits, interleaved, ms / steps, bytes / (ms / steps * 1e-3) / 1e9, bytes);
+#ifdef DEC_STAMPS
+    {   // where one launch's time goes: the stamps wave 0 of every work group left (100 MHz counter), relative to the
+        // earliest work group's entry
+        step(0);
+        CK(hipStreamSynchronize(st));
+        const int groups = std::min(bs * splits, 8192);
+        std::vector<unsigned long long> raw((size_t)groups * 6);
+        msgl_decode_stamps(raw.data(), groups);
+        unsigned long long t0 = ~0ull;
+        for (int g = 0; g < groups; ++g)
+            if (raw[(size_t)g * 6]) t0 = std::min(t0, raw[(size_t)g * 6]);
+        const char* what[6] = {"entry", "page-table entries at hand", "first K tile landed", "tile loop done", "waves met", "partials stored"};
+        for (int i = 0; i < 6; ++i) {
+            std::vector<double> v;
+            for (int g = 0; g < groups; ++g)
+                if (raw[(size_t)g * 6] && raw[(size_t)g * 6 + i] >= t0) v.push_back((double)(raw[(size_t)g * 6 + i] - t0) * 0.01);
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end());
+            printf("  stamp %d %-28s min %6.2f  median %6.2f  p90 %6.2f  max %6.2f us  (%zu groups)\n", i, what[i], v.front(), v[v.size() / 2],
+                   v[v.size() * 9 / 10], v.back(), v.size());
+        }
+    }
+#endif
     return 0;
 }
