@@ -571,9 +571,8 @@ def build_extend_config(Hq, Hkv, ps, Sq, prefix, seed=31, dev=None):
     idx = torch.zeros(1, dtype=torch.int32, device=dev)
     cu = torch.tensor([0, Sq], dtype=torch.int32, device=dev)
     pre = torch.tensor([prefix], dtype=torch.int32, device=dev)
-    ws = None
-    if -(-Sq // 128) * max(1, Hq // 2) < torch.cuda.get_device_properties(dev).multi_processor_count and S >= 2048:
-        ws = torch.empty(ops.extend_workspace_bytes(Sq, Hq, D), dtype=torch.uint8, device=dev)
+    ks = ops.extend_key_splits(1, Sq, S, Hq, Hkv)
+    ws = torch.empty(ops.extend_workspace_bytes_for(Sq, Hq, D, ks), dtype=torch.uint8, device=dev) if ks > 1 else None
 
     def launch():
         ops.paged_extend(q, kv[:, 0], kv[:, 1], r2t, idx, cu, pre, Sq, D ** -0.5, ps, out=out, max_seqlen_k=S, workspace=ws)

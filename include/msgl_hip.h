@@ -242,6 +242,12 @@ int msgl_shared_prefix_decode(const void* q, int64_t q_stride,
  * group each, and a second small kernel joins the partial results; without it such a launch
  * leaves compute units idle or half occupied.  Results agree to fp32 rounding of the sums. */
 size_t msgl_paged_extend_workspace_bytes(int64_t total_tokens, int Hq, int D);
+/* The same, sized for the launch at hand instead of the worst case: msgl_paged_extend_key_splits returns the number of
+ * key runs (1..8, 1 = no split) the library takes for a batch of bs requests with these bounds when the workspace
+ * allows, and msgl_paged_extend_workspace_bytes_for the bytes that many runs need (0 for key_splits <= 1).  A smaller
+ * workspace than that is legal too: the library then takes as many runs as fit. */
+int msgl_paged_extend_key_splits(int bs, int max_seqlen_q, int max_seqlen_k, int Hq, int Hkv);
+size_t msgl_paged_extend_workspace_bytes_for(int64_t total_tokens, int Hq, int D, int key_splits);
 
 int msgl_paged_extend(const void* q, int64_t q_stride,
                       const void* k_cache, const void* v_cache, int64_t cache_stride,

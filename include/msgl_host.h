@@ -9,6 +9,8 @@
  * (cache_unfinished_req / cache_finished_req, radix_cache.py:270-365) stay in the Python mirror
  * (mini_sglang_amd/mem_cache/radix_cache.py) because they edit torch tensors.
  *
+ * Page allocator: see the second half of this header.
+ *
  * Node handles are int64 ids; 0 is the root.  A handle stays valid while the node exists: splitting a node keeps
  * the id on the LOWER part (as the reference keeps the object), eviction deletes ids of unlocked leaves only.
  */
@@ -52,6 +54,38 @@ int64_t msgl_radix_evict(msgl_radix* t, int64_t num_tokens, int32_t* slots, int6
 int64_t msgl_radix_evictable_size(const msgl_radix* t);
 int64_t msgl_radix_protected_size(const msgl_radix* t);
 int64_t msgl_radix_node_count(const msgl_radix* t);
+
+/* ---------------------------------------------------------------------------
+ * Page allocator of the KV pool.  Replaces PageAllocator (mini_sglang/mem_cache/token2kv.py:154-212): page p owns
+ * slots [p * page_size, (p + 1) * page_size); pages 1..page_num start free in ascending order (page 0 is the dummy
+ * page padded rows write to); alloc takes from the FRONT of the free list, free appends at the BACK in the order
+ * given.  The order is part of the contract: it decides every slot a request gets.
+ * ------------------------------------------------------------------------- */
+typedef struct msgl_pages msgl_pages;
+
+/* PageAllocator.__init__ / clear (token2kv.py:166-183, 209-212).  NULL on failure. */
+msgl_pages* msgl_pages_create(int64_t page_num, int page_size);
+void msgl_pages_destroy(msgl_pages* a);
+void msgl_pages_clear(msgl_pages* a);
+
+/* len(free_page): available_size() = free pages * page_size (token2kv.py:185-186). */
+int64_t msgl_pages_free_count(const msgl_pages* a);
+
+/* alloc (token2kv.py:188-202): the first num free pages, in list order, into out[0..num).  Returns num, or -1 when
+ * fewer are free (nothing is taken; the mirror raises the reference's RuntimeError), -2 for bad arguments. */
+int64_t msgl_pages_alloc(msgl_pages* a, int64_t num, int32_t* out);
+
+/* free (token2kv.py:204-207): appends pages[0..n) at the back.  Returns the new number of free pages, or -1 when
+ * an id is outside 1..page_num (nothing is added), -2 for bad arguments. */
+int64_t msgl_pages_free(msgl_pages* a, const int32_t* pages, int64_t n);
+
+/* The free list in order, for callers that mirror it elsewhere (the device-side decode preparation keeps a copy in
+ * HBM): copies min(free count, cap) ids to out and returns the free count. */
+int64_t msgl_pages_peek(const msgl_pages* a, int32_t* out, int64_t cap);
+
+/* Replaces the free list by pages[0..n) (the reference's callers assign `free_page` directly when they lay out a
+ * pool by hand).  Returns n, or -1 for an id outside 1..page_num (list unchanged). */
+int64_t msgl_pages_assign(msgl_pages* a, const int32_t* pages, int64_t n);
 
 #ifdef __cplusplus
 }

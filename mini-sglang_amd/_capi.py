@@ -50,6 +50,8 @@ SIGNATURES = {
          c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_int64, c_void_p],
     ),
     "msgl_paged_extend_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "msgl_paged_extend_key_splits": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "msgl_paged_extend_workspace_bytes_for": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "msgl_extend_plan_items": (c_int64, [c_int, c_int]),
     "msgl_extend_plan": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "msgl_rmsnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),

@@ -24,6 +24,14 @@ SIGNATURES = {
     "msgl_radix_evictable_size": (c_int64, [c_void_p]),
     "msgl_radix_protected_size": (c_int64, [c_void_p]),
     "msgl_radix_node_count": (c_int64, [c_void_p]),
+    "msgl_pages_create": (c_void_p, [c_int64, c_int]),
+    "msgl_pages_destroy": (None, [c_void_p]),
+    "msgl_pages_clear": (None, [c_void_p]),
+    "msgl_pages_free_count": (c_int64, [c_void_p]),
+    "msgl_pages_alloc": (c_int64, [c_void_p, c_int64, _I32P]),
+    "msgl_pages_free": (c_int64, [c_void_p, _I32P, c_int64]),
+    "msgl_pages_peek": (c_int64, [c_void_p, _I32P, c_int64]),
+    "msgl_pages_assign": (c_int64, [c_void_p, _I32P, c_int64]),
 }
 
 

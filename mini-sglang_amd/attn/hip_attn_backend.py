@@ -118,11 +118,11 @@ class HipAttnBackend(AttentionBackend):
         """Room for key-split partials when the extend launch would not cover the chip (few 128-row query tiles x head
         pairs with long key ranges: a short prompt on a long cached prefix, few heads per rank); None otherwise.  Extend
         is never captured, so the buffer may grow between forwards."""
-        pairs = layer.num_heads // (2 if (layer.num_heads // layer.num_kv_heads) % 2 == 0 else 1)
-        items = batch.seq_lens.numel() * -(-md.max_seqlen_q // 128) * pairs
-        if md.max_seqlen_k < 2048 or items >= self._cus:
+        ks = ops.extend_key_splits(batch.seq_lens.numel(), md.max_seqlen_q, md.max_seqlen_k, layer.num_heads, layer.num_kv_heads)
+        if ks <= 1:
             return None
-        need = ops.extend_workspace_bytes(T, layer.num_heads, layer.head_dim)
+        # sized for the runs the library will take for this launch (not for the worst case of eight)
+        need = ops.extend_workspace_bytes_for(T, layer.num_heads, layer.head_dim, ks)
         if self._extend_workspace is None or self._extend_workspace.numel() < need:
             self._extend_workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._extend_workspace

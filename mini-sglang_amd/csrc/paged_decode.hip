@@ -496,34 +496,43 @@ __global__ __launch_bounds__(256) void paged_decode_merge_kernel(DecodeParams p)
     }
 }
 
-// The same merge for at most 64 splits: one WAVE per (request, query head), no LDS and no barrier — lane s
-// holds split s's (max, sum) pair, the weights stay in registers and are broadcast with a lane read.
+// The same merge for at most 16 splits: one WAVE per (request, query head), no LDS and no barrier -- lane s holds split
+// s's (max, sum) pair, the weights stay in registers and are broadcast with a lane read.  The partial outputs of the
+// first four splits are requested before the number of splits is known (it hangs on a load of the request's length;
+// slots below max_splits are inside the workspace, and what an unused one holds is discarded), the rest four at a time.
 __global__ __launch_bounds__(256) void paged_decode_merge_small_kernel(DecodeParams p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);  // (request, query head)
     if (row >= p.bs * p.Hq) return;
     const int b = row / p.Hq;
     const int hq = row - b * p.Hq;
+    const int64_t row0 = ((int64_t)b * p.max_splits) * p.Hq + hq;
+    const int d = lane * 2;
+    const float* src = p.ws_o + row0 * kD + d;
+    const int64_t step = (int64_t)p.Hq * kD;
+    float2 o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) o[u] = *reinterpret_cast<const float2*>(src + (int64_t)min(u, p.max_splits - 1) * step);
+    const float2 ml_raw = *reinterpret_cast<const float2*>(p.ws_ml + (row0 + (int64_t)min(lane, p.max_splits - 1) * p.Hq) * 2);
     const SplitInfo si = split_info(p, b, split_chunk(p));
     const int nsplit = min(si.nsplit + si.extra, p.max_splits);
     if (nsplit <= 1 && si.extra == 0) return;  // written directly by the main kernel
-    const int64_t row0 = ((int64_t)b * p.max_splits) * p.Hq + hq;
-    const float2 ml = lane < nsplit ? *reinterpret_cast<const float2*>(p.ws_ml + (row0 + (int64_t)lane * p.Hq) * 2)
-                                    : make_float2(kNegBig, 0.f);
+    const float2 ml = lane < nsplit ? ml_raw : make_float2(kNegBig, 0.f);
     float M = ml.x;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off));
     const float w = lane < nsplit ? fast_exp2(ml.x - M) : 0.f;
     const float L = wave_sum(w * ml.y);
-    const int d = lane * 2;
-    const float* src = p.ws_o + row0 * kD + d;
-    const int64_t step = (int64_t)p.Hq * kD;
     float o0 = 0.f, o1 = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float2 o = *reinterpret_cast<const float2*>(src + (int64_t)s * step);
-        const float f = __shfl(w, s);
-        o0 = fmaf(f, o.x, o0);
-        o1 = fmaf(f, o.y, o1);
+    for (int s0 = 0; s0 < nsplit; s0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + u;
+            if (s0 != 0 && s < nsplit) o[u] = *reinterpret_cast<const float2*>(src + (int64_t)s * step);
+            const float f = s < nsplit ? __shfl(w, s & 63) : 0.f;
+            o0 = fmaf(f, s < nsplit ? o[u].x : 0.f, o0);
+            o1 = fmaf(f, s < nsplit ? o[u].y : 0.f, o1);
+        }
     }
     const float inv = 1.0f / L;
     *reinterpret_cast<uint32_t*>(p.out + (int64_t)b * p.out_stride + hq * kD + d) = pack_bf16(o0 * inv, o1 * inv);

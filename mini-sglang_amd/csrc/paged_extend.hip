@@ -579,6 +579,36 @@ extern "C" size_t msgl_paged_extend_workspace_bytes(int64_t total_tokens, int Hq
     return (size_t)total_tokens * Hq * kMaxKeySplit * (D + 2) * sizeof(float);
 }
 
+// Key runs per work item the launch of msgl_paged_extend takes for this shape when its workspace allows (1 = no split):
+// few work items with long key ranges (a short prompt on a long cached prefix, few heads per GPU) cut every item's key
+// tiles until the launch covers the chip, at least eight key tiles per run.
+static int extend_key_splits(int bs, int max_seqlen_q, int max_seqlen_k, int Hq, int Hkv) {
+    const int group = Hq / Hkv;
+    int nh = (group % 2 == 0) ? 2 : 1;
+    const int nh_forced = variant(MSGL_VARIANT_EXTEND_HEADS);
+    if (nh_forced > 0) nh = (nh_forced == 2 && group % 2 == 0) ? 2 : 1;
+    const int64_t items = (int64_t)bs * ((max_seqlen_q + kBM - 1) / kBM) * (Hq / nh);
+    const int cus = device_cus();
+    if (!(max_seqlen_k >= 2048 && items < cus)) return 1;
+    int ks = (int)((cus + items - 1) / items);
+    const int by_keys = (max_seqlen_k / kBN) / 8;
+    ks = ks > kMaxKeySplit ? kMaxKeySplit : ks;
+    ks = ks > by_keys ? by_keys : ks;
+    if (const int f = variant(MSGL_VARIANT_EXTEND_KEY_SPLIT); f > 0) ks = f > kMaxKeySplit ? kMaxKeySplit : f;
+    return ks < 1 ? 1 : ks;
+}
+
+extern "C" int msgl_paged_extend_key_splits(int bs, int max_seqlen_q, int max_seqlen_k, int Hq, int Hkv) {
+    if (bs <= 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0) return 1;
+    return extend_key_splits(bs, max_seqlen_q, max_seqlen_k, Hq, Hkv);
+}
+
+extern "C" size_t msgl_paged_extend_workspace_bytes_for(int64_t total_tokens, int Hq, int D, int key_splits) {
+    if (total_tokens <= 0 || Hq <= 0 || D <= 0 || key_splits <= 1) return 0;
+    const int ks = key_splits > kMaxKeySplit ? kMaxKeySplit : key_splits;
+    return (size_t)total_tokens * Hq * ks * (D + 2) * sizeof(float);
+}
+
 extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
                                  int64_t cache_stride, const int32_t* req_to_token, int64_t r2t_stride,
                                  const int32_t* req_pool_indices, const int32_t* cu_seqlens_q, const int32_t* prefix_lens,
@@ -630,15 +660,11 @@ extern "C" int msgl_paged_extend(const void* q, int64_t q_stride, const void* k_
     // doubles the number of groups instead (one wave per SIMD: about a fifth slower per group).
     const int64_t items = (int64_t)bs * p.tiles_per_req * (Hq / nh);
     const int cus = device_cus();
-    const bool want_split = max_seqlen_k >= 2048 && items < cus;
-    if (want_split && workspace != nullptr && total_tokens > 0) {
+    const int ks_wanted = extend_key_splits(bs, max_seqlen_q, max_seqlen_k, Hq, Hkv);
+    if (ks_wanted > 1 && workspace != nullptr && total_tokens > 0) {
         MSGL_REQUIRE(aligned16(workspace), "msgl_paged_extend: workspace must be 16-byte aligned");
         const size_t per_split = (size_t)total_tokens * Hq * (D + 2) * sizeof(float);
-        int ks = (int)((cus + items - 1) / items);
-        const int by_keys = (max_seqlen_k / kBN) / 8;  // at least eight key tiles per run
-        ks = ks > kMaxKeySplit ? kMaxKeySplit : ks;
-        ks = ks > by_keys ? by_keys : ks;
-        if (const int f = variant(MSGL_VARIANT_EXTEND_KEY_SPLIT); f > 0) ks = f > kMaxKeySplit ? kMaxKeySplit : f;
+        int ks = ks_wanted;
         if ((size_t)ks * per_split > workspace_bytes) ks = (int)(workspace_bytes / per_split);
         if (ks > 1) {
             p.ksplit = ks;

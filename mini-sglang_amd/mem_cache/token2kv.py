@@ -63,26 +63,66 @@ class MHAKVPool:
 
 class PageAllocator:
     """Free list of page ids 1..page_num; page p owns slots [p*page_size, (p+1)*page_size)
-    (mini_sglang/mem_cache/token2kv.py:154-212).  Kept on the host: allocation is control-plane work."""
+    (mini_sglang/mem_cache/token2kv.py:154-212).  Kept on the host: allocation is control-plane work.  The list itself
+    lives in libmsgl_host.so (a ring buffer behind ``msgl_pages_*``): alloc takes from the front, free appends at the
+    back, as the reference's tensor slicing / concatenation does, at the cost of the pages moved instead of the length
+    of the list.  ``free_page`` stays readable and assignable as a tensor, which is how the reference's callers (and
+    this package's synthetic workloads) inspect and lay out a pool."""
 
     def __init__(self, page_num: int, page_size: int, device: str = "cpu"):
+        from .. import _capi_host
+
+        self._lib = _capi_host.lib
         self.page_num = page_num
         self.page_size = page_size
         self.device = device
-        self.clear()
+        self._h = self._lib.msgl_pages_create(int(page_num), int(page_size))
+        if not self._h:
+            raise ValueError(f"PageAllocator: page_num={page_num} page_size={page_size}")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.msgl_pages_destroy(h)
+
+    @staticmethod
+    def _ptr(t: torch.Tensor):
+        import ctypes
+
+        return ctypes.cast(t.data_ptr(), ctypes.POINTER(ctypes.c_int32))
+
+    def free_count(self) -> int:
+        return int(self._lib.msgl_pages_free_count(self._h))
 
     def available_size(self) -> int:
-        return self.free_page.numel() * self.page_size
+        return self.free_count() * self.page_size
 
     def alloc(self, num: int) -> torch.Tensor:
-        if num > self.free_page.numel():
+        out = torch.empty(max(int(num), 0), dtype=torch.int32)
+        got = self._lib.msgl_pages_alloc(self._h, int(num), self._ptr(out))
+        if got != num:
             raise RuntimeError(
-                f"Not enough free pages available. need {num}, free {self.free_page.numel()}, total {self.page_num}")
-        got, self.free_page = self.free_page[:num], self.free_page[num:]
-        return got
+                f"Not enough free pages available. need {num}, free {self.free_count()}, total {self.page_num}")
+        return out
 
     def free(self, page_ids: torch.Tensor) -> None:
-        self.free_page = torch.cat([self.free_page, page_ids.to("cpu", torch.int32)], dim=0)
+        ids = page_ids.to("cpu", torch.int32).contiguous().view(-1)
+        if self._lib.msgl_pages_free(self._h, self._ptr(ids), ids.numel()) < 0:
+            raise ValueError(f"PageAllocator.free: page id outside 1..{self.page_num}")
 
     def clear(self) -> None:
-        self.free_page = torch.arange(1, self.page_num + 1, dtype=torch.int32)
+        self._lib.msgl_pages_clear(self._h)
+
+    @property
+    def free_page(self) -> torch.Tensor:
+        """The free list in allocation order (a copy)."""
+        n = self.free_count()
+        out = torch.empty(n, dtype=torch.int32)
+        self._lib.msgl_pages_peek(self._h, self._ptr(out), n)
+        return out
+
+    @free_page.setter
+    def free_page(self, pages: torch.Tensor) -> None:
+        ids = pages.to("cpu", torch.int32).contiguous().view(-1)
+        if self._lib.msgl_pages_assign(self._h, self._ptr(ids), ids.numel()) < 0:
+            raise ValueError(f"PageAllocator.free_page: page id outside 1..{self.page_num}")

@@ -436,6 +436,16 @@ def extend_workspace_bytes(total_tokens: int, Hq: int, D: int) -> int:
     return int(_lib.msgl_paged_extend_workspace_bytes(int(total_tokens), Hq, D))
 
 
+def extend_key_splits(bs: int, max_seqlen_q: int, max_seqlen_k: int, Hq: int, Hkv: int) -> int:
+    """Key runs per work item paged_extend takes for this shape when its workspace allows (1 = none)."""
+    return int(_lib.msgl_paged_extend_key_splits(int(bs), int(max_seqlen_q), int(max_seqlen_k), int(Hq), int(Hkv)))
+
+
+def extend_workspace_bytes_for(total_tokens: int, Hq: int, D: int, key_splits: int) -> int:
+    """Workspace bytes of paged_extend for `key_splits` key runs (0 for one run)."""
+    return int(_lib.msgl_paged_extend_workspace_bytes_for(int(total_tokens), int(Hq), int(D), int(key_splits)))
+
+
 def extend_plan_items(bs: int, max_seqlen_q: int) -> int:
     return int(_lib.msgl_extend_plan_items(int(bs), int(max_seqlen_q)))
 

@@ -149,7 +149,7 @@ def test_host_library_exports_every_declared_symbol():
     import re
     from mini_sglang_amd import _capi_host
     header = open(os.path.join(ROOT, "include", "msgl_host.h")).read()
-    declared = set(re.findall(r"\b(msgl_radix_\w+)\s*\(", header))
+    declared = set(re.findall(r"\b(msgl_(?:radix|pages)_\w+)\s*\(", header))
     assert declared == set(_capi_host.SIGNATURES), declared ^ set(_capi_host.SIGNATURES)
     for name in declared:
         assert hasattr(_capi_host.lib, name)
