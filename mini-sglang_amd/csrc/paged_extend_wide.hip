@@ -55,7 +55,7 @@ __device__ __forceinline__ float add_alone(float a, float b) {
 
 // Diagnostic builds only (-DEXT_KO=mask, scripts/ab_extend.sh): parts of the steady-state loop left out to see what each
 // costs; the results of such a build are wrong.  1 exponent fma, 2 exponential, 4 lane sums, 8 packs, 16 ring writes,
-// 32 ring loads, 64 K fragment reads, 128 V^T fragment reads.
+// 32 ring loads, 64 K fragment reads, 128 V^T fragment reads, 256 the barrier.
 #ifndef EXT_KO
 #define EXT_KO 0
 #endif
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
         STAMP(0);
         // LDS operations of a wave complete in order, and the K fragments read in block 4 were waited for: every ring
         // write of the iteration before (all issued before those reads) has landed
-        asm volatile("s_barrier" ::: "memory");
+        if (!(kKo & 256)) asm volatile("s_barrier" ::: "memory");
         STAMP(1);
         short8_t vg[4];
         uint4 ka[KD + 1];

@@ -195,6 +195,10 @@ E2E_CASES = {
     # logits of all 256 steps
     "qwen3_0.6b_ps1_random_head": (dict(max_position_embeddings=2048, tie_word_embeddings=False, lm_head_std=0.005), 1, (47, [23, 9]), 256, 13,
                                    0.01, 0.3, 0.0),
+    # Qwen3-8B layer shapes (hidden 4096, 32 q / 8 kv heads, intermediate 12288, full vocabulary) on four layers, page_size
+    # 16, batch 3 with a prompt that ends on a page boundary: the widths the benchmark runs, at a depth the host can compute
+    "qwen3_8b_l4_ps16": (dict(hidden_size=4096, num_hidden_layers=4, num_attention_heads=32, num_key_value_heads=8, intermediate_size=12288,
+                              max_position_embeddings=2048, tie_word_embeddings=False), 16, (51, [40, 17, 64]), 40, 17, 0.006, 0.3, 0.02),
 }
 WIDE_COLS = 2048
 

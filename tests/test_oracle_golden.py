@@ -61,7 +61,20 @@ def test_e2e_fixture_matches_oracle_harness(name):
         assert torch.equal(got[key], fx[key]), key
 
 
-@pytest.mark.parametrize("name", ["tiny_ps1", "tiny_ps16", "qwen3_0.6b_ps1"])
+def test_e2e_8b_layer_shapes_fixture_matches_oracle_harness():
+    """Qwen3-8B widths on four layers (page_size 16, batch 3): the first six steps of the oracle stack on the host equal the
+    reference's run bit for bit (the whole 40 steps take the host several minutes; the GPU test covers all of them)."""
+    name, steps = "qwen3_8b_l4_ps16", 6
+    fx = gc.load(f"e2e_{name}.pt")
+    got = gc.run_e2e(name, "cpu", layers=mo, backend_factory=mo.OracleAttnBackend, new_tokens=steps)
+    assert torch.equal(got["tokens"], fx["tokens"][:, :steps])
+    for key in ("margins", "top1_logits", "logits_slices", "logits_wide"):
+        assert torch.equal(got[key], fx[key][:steps]), key
+    assert torch.equal(got["out_cache_loc_first"], fx["out_cache_loc_first"])
+    assert torch.equal(got["out_cache_loc_decode"], fx["out_cache_loc_decode"][: steps - 1])
+
+
+@pytest.mark.parametrize("name", ["tiny_ps1", "tiny_ps16", "qwen3_0.6b_ps1", "qwen3_8b_l4_ps16"])
 def test_prepare_decode_oracle_matches_reference_slots(name):
     """The decode-step preparation restated in the oracle reproduces the slots the REFERENCE assigned in its own
     run of the case (fixture fields out_cache_loc_first / out_cache_loc_decode / req_to_token_rows)."""
