@@ -154,3 +154,58 @@ def test_decode_and_extend_plan_restatements():
     items, cost = orc.extend_plan_ref([0, 300, 301], [64, 1000], 300)
     # 3 query tiles per request slot; request 0: 300 rows on a 64 prefix; request 1: one row on 1000
     assert dict(zip(items, cost)) == {0: 3, 1: 5, 2: 6, 3: 16}
+
+
+def _sgprs(operand_text):
+    """Scalar registers named in an operand string: s7 -> {7}, s[4:7] -> {4, 5, 6, 7}."""
+    import re
+    regs = set()
+    for m in re.finditer(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b", operand_text):
+        if m.group(3) is not None:
+            regs.add(int(m.group(3)))
+        else:
+            regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return regs
+
+
+def test_scalar_page_table_loads_of_the_matrix_core_decode_kernel_are_waited_for_before_any_use(tmp_path):
+    """paged_decode_mfma_kernel fetches page-table entries with s_load_dword in one asm statement and waits for them in
+    another, so the compiler does not know that the register is in flight in between.  This reads the built code object:
+    between every such load and the next s_waitcnt lgkmcnt(0), no instruction may name the loaded register (a copy made
+    there would copy the register's old contents, and the kernel would then read K/V at a wrong slot)."""
+    import re
+    import shutil
+    import subprocess
+    lib = os.path.join(ROOT, "mini-sglang_amd", "libmsgl_hip.so")
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(lib) and os.path.exists(objdump)):
+        pytest.skip("needs the built library and llvm-objdump")
+    shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp_path, check=True, capture_output=True)
+    checked = 0
+    for co in sorted(tmp_path.glob("*gfx950")):
+        text = subprocess.run([objdump, "-d", str(co)], check=True, capture_output=True, text=True).stdout
+        for fn in re.split(r"\n(?=[0-9a-f]+ <)", text):
+            if "paged_decode_mfma_kernel" not in fn.split("\n", 1)[0]:
+                continue
+            pending = {}   # register -> line of its load
+            for line in fn.split("\n")[1:]:
+                ins = line.split("//")[0].strip()
+                if not ins:
+                    continue
+                op, _, rest = ins.partition(" ")
+                if op == "s_waitcnt" and "lgkmcnt(0)" in rest:
+                    pending.clear()
+                    continue
+                named = _sgprs(rest)
+                if op == "s_load_dword":
+                    dst = _sgprs(rest.split(",")[0])
+                    src = named - dst
+                    assert not (src & pending.keys()), f"address of a scalar load uses a register still in flight: {ins}"
+                    for r in dst:
+                        pending[r] = ins
+                    checked += 1
+                    continue
+                hit = named & pending.keys()
+                assert not hit, f"{ins!r} names s{sorted(hit)[0]} between {pending[sorted(hit)[0]]!r} and its wait"
+    assert checked >= 8, f"expected the kernel's scalar page-table loads in the code object, saw {checked}"
