@@ -699,6 +699,17 @@ def layer_kernels(args, world, rank):
             record("store_kv", T, T * (4 * Hkv * D * 2 + 4), store, launches)
             del qkvs, kvs
             torch.cuda.empty_cache()
+        # greedy head: product with this rank's vocabulary rows and arg-max in one pass over the rows, beside the
+        # unfused pair it replaces (library GEMM writing [bs, vocab / tp] logits, then msgl_argmax_val)
+        vocab = 151936 // world
+        head = (torch.randn(vocab, hid, device=dev) * 0.02).bfloat16()
+        for bs in (64, 128):
+            hx = torch.randn(bs, hid, device=dev).bfloat16()
+            hws = ops.lm_head_argmax_workspace(bs, vocab, dev)
+            record("lm_head_argmax", bs, vocab * hid * 2 + bs * hid * 2, lambda i: ops.lm_head_argmax(hx, head, workspace=hws), 4)
+            per = time_graph(lambda i: ops.argmax(torch.nn.functional.linear(hx, head), return_values=True), 4, reps=7)
+            out["ops"][f"lm_head_argmax_T{bs}"]["gemm_then_argmax_us"] = spread([x * 1e3 for x in per], 2)
+        del head
     except Exception as e:  # noqa: BLE001
         out["error"] = f"{type(e).__name__}: {e}"[:300]
     torch.cuda.empty_cache()

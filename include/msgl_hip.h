@@ -336,6 +336,23 @@ int msgl_argmax(const void* logits, int64_t row_stride, int elem_bytes, int32_t*
 int msgl_argmax_val(const void* logits, int64_t row_stride, int elem_bytes, int32_t* out, float* out_val,
                     int bs, int vocab, void* stream);
 
+/* Greedy token straight from the final hidden state, for decode-sized batches: out[b] = argmax_v bf16(x[b, :] . w[v, :]),
+ * first index on ties, NaN largest; out_val[b] = that logit as fp32 (NULL = not wanted).  Replaces
+ * LogitsProcessor._get_logits + the temperature == 0 branch of Sampler.forward
+ * (mini_sglang/layers/logits_processor.py:56-59, mini_sglang/layers/sampler.py:14-15) on one rank's vocabulary shard
+ * (ParallelLMHead rows, mini_sglang/layers/embed_head.py:56-80) without writing the [bs, vocab] logits: the product is
+ * accumulated in fp32 on the matrix cores, rounded to bf16 as F.linear's output would be, and reduced in the same pass.
+ * Under tensor parallelism the ranks then exchange bs (value, index) pairs, as with msgl_argmax_val.
+ *   x: [bs, hidden] bf16, row stride x_stride elements; w: [vocab, hidden] bf16, row stride w_stride (both 16-byte
+ *   aligned, strides multiples of 8); hidden a multiple of 256; out: int32 [bs] (row index inside w).
+ *   workspace: msgl_lm_head_argmax_workspace_bytes(bs, vocab) bytes of device memory (partial winners per block of
+ *   128 rows), contents irrelevant before and after.  Sums differ from another GEMM's in the last fp32 bits, so a logit
+ *   can round to the neighbouring bf16 value: the token equals argmax(F.linear(x, w)) whenever the top two logits are
+ *   more than one bf16 ulp apart. */
+size_t msgl_lm_head_argmax_workspace_bytes(int bs, int vocab);
+int msgl_lm_head_argmax(const void* x, int64_t x_stride, const void* w, int64_t w_stride, int32_t* out, float* out_val,
+                        int bs, int vocab, int hidden, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Decode-step preparation on the device.  Replaces BatchInfo.prepare_for_decode
  * (mini_sglang/managers/batch_info.py:247-302) together with the allocator call inside it

@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSGL_HIP_LIB", os.path.join(_HERE, "libmsgl_hip.so"))
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 # name -> (restype, argtypes); mirrors include/msgl_hip.h and include/msgl_comm.h one to one
 SIGNATURES = {
@@ -68,6 +68,8 @@ SIGNATURES = {
     ),
     "msgl_argmax": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_void_p]),
     "msgl_argmax_val": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "msgl_lm_head_argmax_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "msgl_lm_head_argmax": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "msgl_prepare_decode": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,

@@ -555,6 +555,34 @@ def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None, return_valu
     return (out, vals) if return_values else out
 
 
+def lm_head_argmax_workspace(bs: int, vocab: int, device) -> torch.Tensor:
+    """Scratch tensor for ``lm_head_argmax`` at this batch size and (local) vocabulary; contents never matter."""
+    return torch.empty(int(_lib.msgl_lm_head_argmax_workspace_bytes(int(bs), int(vocab))), dtype=torch.uint8, device=device)
+
+
+def lm_head_argmax(hidden: torch.Tensor, weight: torch.Tensor, workspace: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None):
+    """Greedy token and its logit straight from the final hidden state [bs, hidden] and the head's rows
+    [vocab, hidden] (both bf16): ``(argmax, max)`` of ``F.linear(hidden, weight)`` per row, int32 [bs] and fp32 [bs], without
+    the logits being written anywhere (see msgl_lm_head_argmax).  ``workspace``: from ``lm_head_argmax_workspace``
+    (allocated here when omitted; a captured step passes its own)."""
+    _need(hidden.is_cuda and weight.is_cuda and hidden.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16,
+          "hidden and weight must be bf16 on the GPU")
+    _need(hidden.dim() == 2 and weight.dim() == 2 and hidden.shape[1] == weight.shape[1] and hidden.stride(1) == 1 and weight.stride(1) == 1,
+          "hidden [bs, k] and weight [vocab, k] with unit inner stride")
+    bs, k = hidden.shape
+    vocab = weight.shape[0]
+    if workspace is None:
+        workspace = lm_head_argmax_workspace(bs, vocab, hidden.device)
+    if out is None:
+        out = torch.empty(bs, dtype=torch.int32, device=hidden.device)
+    _dev_i32(out, "out")
+    vals = torch.empty(bs, dtype=torch.float32, device=hidden.device)
+    _check(_lib.msgl_lm_head_argmax(hidden.data_ptr(), hidden.stride(0), weight.data_ptr(), weight.stride(0), out.data_ptr(), vals.data_ptr(),
+                                    bs, vocab, k, workspace.data_ptr(), workspace.numel(), _stream()))
+    return out, vals
+
+
 def prepare_decode(req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, last_slots: torch.Tensor, free_pages: torch.Tensor,
                    free_range: torch.Tensor, req_to_token: torch.Tensor, positions: torch.Tensor, out_cache_loc: torch.Tensor,
                    status: torch.Tensor, page_size: int, next_tokens: Optional[torch.Tensor] = None,

@@ -44,6 +44,14 @@ class DeviceDecodeLoop:
         self.token_log = torch.zeros((max_steps, bs), **i32)
         self.step_idx = torch.zeros(1, dtype=torch.int64, device=dev)
         self.pending = 0          # steps launched since the last sync_host()
+        # head GEMM and greedy reduction in one kernel (no logits in memory) where the kernel is built for the shape;
+        # its scratch is allocated here, outside the captured step
+        head = mr.model.lm_head
+        # (up to 128 requests the product is bound by the pass over the head's rows and the fused kernel is ahead of
+        # GEMM + argmax; beyond, it would take two passes over the rows and the library GEMM wins)
+        self.fused_head = bool(head.is_cuda and head.dtype == torch.bfloat16 and head.shape[1] % 256 == 0 and bs <= 128
+                               and getattr(mr, "fused_head", True))
+        self.head_ws = ops.lm_head_argmax_workspace(bs, head.shape[0], dev) if self.fused_head else None
         self.seq_lens_cpu = batch.seq_lens_cpu.clone()
         self.static_batch = BatchInfo(
             forward_mode=ForwardMode.DECODE, input_ids=self.input_ids, positions=self.positions, seq_lens=self.seq_lens,
@@ -71,6 +79,9 @@ class DeviceDecodeLoop:
         self.free_range.copy_(torch.tensor([0, fp.numel()], dtype=torch.int32))
         self._free_uploaded = fp.clone()
 
+    def _head_argmax(self, hidden, head_rows):
+        return ops.lm_head_argmax(hidden, head_rows, workspace=self.head_ws)
+
     # one step: prepare -> forward -> argmax -> log
     def _step(self):
         mr = self.mr
@@ -81,7 +92,8 @@ class DeviceDecodeLoop:
             mr.attn_backend.refresh_decode_plan(self.bs, self.seq_lens)
         # greedy sampling on the vocabulary shard of each rank; the ranks exchange (value, index) pairs, not logits
         mr.model.forward_greedy(self.input_ids, self.positions, self.static_batch,
-                                lambda lg: ops.argmax(lg, return_values=True), out=self.next_tokens)
+                                lambda lg: ops.argmax(lg, return_values=True), out=self.next_tokens,
+                                head_argmax_fn=self._head_argmax if self.fused_head else None)
         self.token_log.index_copy_(0, self.step_idx, self.next_tokens.view(1, -1))
         self.step_idx.add_(1)
 

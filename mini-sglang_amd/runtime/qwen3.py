@@ -190,14 +190,21 @@ class Qwen3ForCausalLM(nn.Module):
             logits = torch.cat(tp_all_gather(logits), dim=-1)
         return logits
 
-    def forward_greedy(self, input_ids: torch.Tensor, positions: torch.Tensor, batch, argmax_fn, out: Optional[torch.Tensor] = None):
+    def forward_greedy(self, input_ids: torch.Tensor, positions: torch.Tensor, batch, argmax_fn, out: Optional[torch.Tensor] = None,
+                       head_argmax_fn=None):
         """Greedy next tokens, int32 [bs], equal to argmax(forward(...).float(), -1) (sampler.py:14-15) without ever
         materialising the full-vocabulary logits under tensor parallelism: every rank reduces its own vocabulary
         shard with ``argmax_fn(local_logits) -> (index int32 [bs], value fp32 [bs])`` and the ranks exchange bs
         (value, index) pairs — 2 KB at batch 256 instead of the 78 MB all-gather of logits_processor.py:56-64.
-        Ties between shards go to the lower rank, i.e. the lower token id, as a single argmax would decide."""
-        local = F.linear(self.forward_hidden(input_ids, positions, batch), self.lm_head)
-        idx, val = argmax_fn(local)
+        Ties between shards go to the lower rank, i.e. the lower token id, as a single argmax would decide.
+        ``head_argmax_fn(hidden, lm_head_rows) -> (index, value)``, when given, replaces the head GEMM and ``argmax_fn``
+        (logits_processor.py:56-59 + sampler.py:14-15 fused)."""
+        hidden = self.forward_hidden(input_ids, positions, batch)
+        if head_argmax_fn is not None:
+            # head product and reduction in one pass: not even the rank's own [bs, vocab / tp] logits are written
+            idx, val = head_argmax_fn(hidden, self.lm_head)
+        else:
+            idx, val = argmax_fn(F.linear(hidden, self.lm_head))
         idx = pick_sharded_argmax(idx, val, self.vocab_per_rank)
         if out is not None:
             out.copy_(idx)
