@@ -358,12 +358,7 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
         STAMP(0);
         // LDS operations of a wave complete in order, and the K fragments read in block 4 were waited for: every ring
         // write of the iteration before (all issued before those reads) has landed
-#ifdef EXT_SKEW
-        // (timing experiment only: wave w takes the iteration's barrier at slice w * EXT_SKEW, which holds the waves a
-        // fixed distance apart; the ring's hand-over rules are not adapted to it)
-#else
         if (!(kKo & 256)) asm volatile("s_barrier" ::: "memory");
-#endif
         STAMP(1);
         short8_t vg[4];
         uint4 ka[KD + 1];
@@ -379,10 +374,6 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
         const uint32_t kp1 = s1 + k_lane + 32 * KROW, kp2 = s2 + k_lane;
         auto slice = [&](auto gc) __attribute__((always_inline)) {
             constexpr int g = decltype(gc)::value, blk = g >> 4, j = g & 15;
-#ifdef EXT_SKEW
-            if constexpr (EXT_SKEW == 0 ? g == 0 : (g % EXT_SKEW == 0 && g / EXT_SKEW < 4))
-                asm volatile("s_cmp_lg_u32 %0, %1\n\ts_cbranch_scc1 1f\n\ts_barrier\n1:" ::"s"(wave), "n"(EXT_SKEW == 0 ? 0 : g / EXT_SKEW) : "memory", "scc");
-#endif
             // ---- LDS reads: V^T fragments a k-step or more ahead of their use, K fragments two k-steps ahead
             if constexpr (g == 0 && !(kKo & 128)) v_pair(s0, 1, 0, vg);
             if constexpr (g == 1 && !(kKo & 128)) v_pair(s0, 1, 2, vg);
