@@ -261,26 +261,30 @@ def main():
         nbytes = buf.numel() * buf.element_size()
         sink = torch.zeros(64, dtype=torch.int32, device=dev)
         best, sweep = None, {}
-        for unroll, gpc in ((8, 16), (8, 8), (4, 8), (4, 16), (4, 32), (2, 16), (2, 32), (1, 32)):
+        # (unroll, work groups per CU, span KiB): span 0 = grid-stride over the whole buffer, else one work group per
+        # contiguous span, the order in which a gather of whole pages walks memory
+        for unroll, gpc, span in ((8, 16, 0), (8, 8, 0), (4, 8, 0), (4, 16, 0), (4, 32, 0), (2, 16, 0), (2, 32, 0), (1, 32, 0),
+                                  (4, 8, 64), (4, 16, 64), (8, 8, 64), (4, 8, 256), (4, 16, 256), (8, 8, 1024), (4, 16, 1024)):
             for _ in range(2):
-                ops.stream_read(buf, sink, unroll, gpc)
+                ops.stream_read(buf, sink, unroll, gpc, span)
             c = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
             c[0].record()
             for i in range(5):
-                ops.stream_read(buf, sink, unroll, gpc)
+                ops.stream_read(buf, sink, unroll, gpc, span)
                 c[i + 1].record()
             torch.cuda.synchronize()
             ts = sorted(c[i].elapsed_time(c[i + 1]) for i in range(5))
             gbps = nbytes / (ts[2] * 1e-3) / 1e9
-            sweep[f"unroll{unroll}_groups{gpc}"] = round(gbps, 1)
+            sweep[f"unroll{unroll}_groups{gpc}" + (f"_span{span}k" if span else "")] = round(gbps, 1)
             if best is None or gbps > best[0]:
-                best = (gbps, unroll, gpc)
+                best = (gbps, unroll, gpc, span)
         read_gbps = best[0]
         result["roofline"]["measured_stream_read_GBps"] = round(read_gbps, 1)
-        result["roofline"]["stream_read_config"] = {"loads_in_flight_per_lane": best[1], "work_groups_per_cu": best[2], "sweep_GBps": sweep}
+        result["roofline"]["stream_read_config"] = {"loads_in_flight_per_lane": best[1], "work_groups_per_cu": best[2],
+                                                    "span_KiB": best[3], "sweep_GBps": sweep}
         result["roofline"]["stream_read_bytes"] = nbytes
         result["roofline"]["frac_of_measured_stream_read"] = round(achieved / read_gbps, 4)
-        result["roofline"]["yardstick_changed_from"] = "r01: device-to-device copy (read + write); r02: read-only stream, one configuration; r03: best of a sweep"
+        result["roofline"]["yardstick_changed_from"] = "r01: device-to-device copy (read + write); r02: read-only stream, one configuration; r03: best of a sweep over loads in flight, resident groups and grid-stride / span order"
     except Exception as e:
         result["roofline"]["measured_stream_read_error"] = f"{type(e).__name__}: {e}"[:120]
 

@@ -391,6 +391,10 @@ int msgl_stream_read(const void* src, size_t bytes, void* sink, void* stream);
  * groups_per_cu = resident 256-thread work groups per compute unit the grid is capped at (1..64).
  * msgl_stream_read is (8, 16).  bench.py sweeps a few pairs and quotes the best as its yardstick. */
 int msgl_stream_read_cfg(const void* src, size_t bytes, void* sink, int unroll, int groups_per_cu, void* stream);
+/* The same bytes read by contiguous spans of span_kib KiB (a multiple of 4), one work group per span front to back, spans dealt
+ * round robin over at most groups_per_cu resident work groups per compute unit: the order in which a gather of whole KV pages
+ * walks memory.  Part of the yardstick sweep. */
+int msgl_stream_read_span(const void* src, size_t bytes, void* sink, int unroll, int groups_per_cu, int span_kib, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSGL_HIP_LIB", os.path.join(_HERE, "libmsgl_hip.so"))
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 # name -> (restype, argtypes); mirrors include/msgl_hip.h and include/msgl_comm.h one to one
 SIGNATURES = {
@@ -77,6 +77,7 @@ SIGNATURES = {
     ),
     "msgl_stream_read": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "msgl_stream_read_cfg": (c_int, [c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p]),
+    "msgl_stream_read_span": (c_int, [c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_void_p]),
     # include/msgl_comm.h
     "msgl_ar_create": (c_int, [c_int, c_int, c_size_t, ctypes.POINTER(c_void_p)]),
     "msgl_ar_export": (c_int, [c_void_p, c_void_p]),

@@ -28,9 +28,56 @@ __global__ __launch_bounds__(kStreamThreads) void stream_read_kernel(const su32x
     if (x == 0x9E3779B9u) sink[blockIdx.x & 63] = x;
 }
 
+// The same bytes by contiguous spans: work group b reads [b * span, (b + 1) * span) front to back, its 256 lanes on
+// consecutive 16-byte pieces (4 KiB per step, UNROLL steps in flight), the way a gather of whole pages walks memory:
+// every DRAM page a group opens is read to its end by that group.
+template <int UNROLL>
+__global__ __launch_bounds__(kStreamThreads) void stream_read_span_kernel(const su32x4_t* __restrict__ src, int64_t nvec, int64_t span_vec,
+                                                                         uint32_t* __restrict__ sink) {
+    su32x4_t acc = {0u, 0u, 0u, 0u};
+    for (int64_t s0 = (int64_t)blockIdx.x * span_vec; s0 < nvec; s0 += (int64_t)gridDim.x * span_vec) {
+        const int64_t end = s0 + span_vec < nvec ? s0 + span_vec : nvec;
+        int64_t i = s0 + threadIdx.x;
+        for (; i + (UNROLL - 1) * kStreamThreads < end; i += UNROLL * kStreamThreads) {
+            su32x4_t v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(src + i + u * kStreamThreads);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) acc ^= v[u];
+        }
+        for (; i < end; i += kStreamThreads) acc ^= __builtin_nontemporal_load(src + i);
+    }
+    const uint32_t x = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (x == 0x9E3779B9u) sink[blockIdx.x & 63] = x;
+}
+
 }  // namespace msgl
 
 using namespace msgl;
+
+extern "C" int msgl_stream_read_span(const void* src, size_t bytes, void* sink, int unroll, int groups_per_cu, int span_kib, void* stream) {
+    MSGL_REQUIRE(src && sink && aligned16(src), "msgl_stream_read_span: src must be a 16-byte aligned device pointer, sink 256 bytes of device memory");
+    MSGL_REQUIRE(bytes >= 16 && bytes % 16 == 0, "msgl_stream_read_span: %zu bytes, a positive multiple of 16 expected", bytes);
+    MSGL_REQUIRE((unroll == 1 || unroll == 2 || unroll == 4 || unroll == 8) && groups_per_cu >= 1 && groups_per_cu <= 64 && span_kib >= 4 &&
+                     span_kib <= (1 << 20) && span_kib % 4 == 0,
+                 "msgl_stream_read_span: unroll %d (1, 2, 4 or 8), groups_per_cu %d (1..64), span %d KiB (a multiple of 4)", unroll, groups_per_cu,
+                 span_kib);
+    const int64_t nvec = (int64_t)(bytes / 16), span_vec = (int64_t)span_kib * 64;
+    int64_t blocks = (nvec + span_vec - 1) / span_vec;
+    const int64_t cap = (int64_t)device_cus() * groups_per_cu;
+    if (blocks > cap) blocks = cap;
+    const dim3 grid((unsigned)blocks), block(kStreamThreads);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const su32x4_t* s = static_cast<const su32x4_t*>(src);
+    uint32_t* k = static_cast<uint32_t*>(sink);
+    switch (unroll) {
+        case 1: hipLaunchKernelGGL(stream_read_span_kernel<1>, grid, block, 0, st, s, nvec, span_vec, k); break;
+        case 2: hipLaunchKernelGGL(stream_read_span_kernel<2>, grid, block, 0, st, s, nvec, span_vec, k); break;
+        case 4: hipLaunchKernelGGL(stream_read_span_kernel<4>, grid, block, 0, st, s, nvec, span_vec, k); break;
+        default: hipLaunchKernelGGL(stream_read_span_kernel<8>, grid, block, 0, st, s, nvec, span_vec, k); break;
+    }
+    return check_launch("stream_read_span_kernel");
+}
 
 extern "C" int msgl_stream_read_cfg(const void* src, size_t bytes, void* sink, int unroll, int groups_per_cu, void* stream) {
     MSGL_REQUIRE(src && sink && aligned16(src), "msgl_stream_read: src must be a 16-byte aligned device pointer, sink 256 bytes of device memory");

@@ -610,9 +610,13 @@ def prepare_decode(req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, last_
         input_ids.data_ptr() if input_ids is not None else None, status.data_ptr(), bs, page_size, _stream()))
 
 
-def stream_read(buf: torch.Tensor, sink: torch.Tensor, unroll: int = 8, groups_per_cu: int = 16) -> None:
+def stream_read(buf: torch.Tensor, sink: torch.Tensor, unroll: int = 8, groups_per_cu: int = 16, span_kib: int = 0) -> None:
     """Read every byte of `buf` once (16 B per lane, non-temporal, `unroll` loads in flight per lane, at most
-    `groups_per_cu` work groups per compute unit) and store nothing: the benchmark's yardstick."""
+    `groups_per_cu` work groups per compute unit) and store nothing: the benchmark's yardstick.  span_kib > 0: by
+    contiguous spans of that many KiB, one work group per span (msgl_stream_read_span)."""
     _need(buf.is_cuda and buf.is_contiguous() and sink.is_cuda and sink.numel() * sink.element_size() >= 256, "GPU buffers expected")
-    _check(_lib.msgl_stream_read_cfg(buf.data_ptr(), buf.numel() * buf.element_size() // 16 * 16, sink.data_ptr(), int(unroll),
-                                     int(groups_per_cu), _stream()))
+    nbytes = buf.numel() * buf.element_size() // 16 * 16
+    if span_kib > 0:
+        _check(_lib.msgl_stream_read_span(buf.data_ptr(), nbytes, sink.data_ptr(), int(unroll), int(groups_per_cu), int(span_kib), _stream()))
+    else:
+        _check(_lib.msgl_stream_read_cfg(buf.data_ptr(), nbytes, sink.data_ptr(), int(unroll), int(groups_per_cu), _stream()))
