@@ -379,6 +379,15 @@ int msgl_prepare_decode(const int32_t* req_pool_indices, int32_t* seq_lens, int3
                         int32_t* positions, int32_t* out_cache_loc,
                         const int32_t* next_tokens, int32_t* input_ids,
                         int32_t* status, int bs, int page_size, void* stream);
+/* The same, also keeping a page table: req_to_page[req_pool_indices[i], old / page_size] = page id whenever request i
+ * takes a page (page_size > 1; NULL = no page table).  Replaces the page half of ReqToTokenPool's bookkeeping
+ * (mini_sglang/mem_cache/req2token.py:43-51, 77-91) for steps prepared on the device; r2p_stride in elements. */
+int msgl_prepare_decode_paged(const int32_t* req_pool_indices, int32_t* seq_lens, int32_t* last_slots,
+                              const int32_t* free_pages, int32_t free_capacity, int32_t* free_range,
+                              int32_t* req_to_token, int64_t r2t_stride, int32_t* req_to_page, int64_t r2p_stride,
+                              int32_t max_ctx, int32_t* positions, int32_t* out_cache_loc,
+                              const int32_t* next_tokens, int32_t* input_ids,
+                              int32_t* status, int bs, int page_size, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Measurement utility (no counterpart in the reference): reads `bytes` bytes at src

@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSGL_HIP_LIB", os.path.join(_HERE, "libmsgl_hip.so"))
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 # name -> (restype, argtypes); mirrors include/msgl_hip.h and include/msgl_comm.h one to one
 SIGNATURES = {
@@ -74,6 +74,11 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
          c_void_p, c_void_p, c_int, c_int, c_void_p],
+    ),
+    "msgl_prepare_decode_paged": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     ),
     "msgl_stream_read": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "msgl_stream_read_cfg": (c_int, [c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p]),

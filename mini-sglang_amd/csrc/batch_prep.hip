@@ -23,6 +23,8 @@ struct PrepParams {
     int32_t* free_range;  // [0] = first page not handed out yet (advanced here), [1] = end of the valid entries
     int32_t* r2t;
     int64_t r2t_stride;
+    int32_t* r2p;  // optional page table: [row][position / page_size] = page id, written when a request takes a page
+    int64_t r2p_stride;
     int32_t max_ctx;
     int32_t* positions;
     int32_t* out_loc;
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(kPrepThreads) void decode_prepare_kernel(PrepParams
             p.out_loc[i] = slot;
             p.last_slots[i] = slot;
             p.r2t[(int64_t)p.req_idx[i] * p.r2t_stride + old] = slot;
+            if (p.r2p && need && p.ps > 1) p.r2p[(int64_t)p.req_idx[i] * p.r2p_stride + old / p.ps] = slot / p.ps;
             if (p.input_ids) p.input_ids[i] = p.next_tokens[i];
         }
         running += chunk_total;
@@ -108,11 +111,11 @@ __global__ __launch_bounds__(kPrepThreads) void decode_prepare_kernel(PrepParams
 
 using namespace msgl;
 
-extern "C" int msgl_prepare_decode(const int32_t* req_pool_indices, int32_t* seq_lens, int32_t* last_slots,
-                                   const int32_t* free_pages, int32_t free_capacity, int32_t* free_range, int32_t* req_to_token,
-                                   int64_t r2t_stride, int32_t max_ctx, int32_t* positions, int32_t* out_cache_loc,
-                                   const int32_t* next_tokens, int32_t* input_ids, int32_t* status, int bs, int page_size,
-                                   void* stream) {
+extern "C" int msgl_prepare_decode_paged(const int32_t* req_pool_indices, int32_t* seq_lens, int32_t* last_slots,
+                                         const int32_t* free_pages, int32_t free_capacity, int32_t* free_range, int32_t* req_to_token,
+                                         int64_t r2t_stride, int32_t* req_to_page, int64_t r2p_stride, int32_t max_ctx,
+                                         int32_t* positions, int32_t* out_cache_loc, const int32_t* next_tokens, int32_t* input_ids,
+                                         int32_t* status, int bs, int page_size, void* stream) {
     if (bs == 0) return MSGL_OK;
     MSGL_REQUIRE(bs > 0 && page_size > 0 && free_capacity >= 0 && max_ctx > 0,
                  "msgl_prepare_decode: bs=%d page_size=%d free_capacity=%d max_ctx=%d", bs, page_size, free_capacity, max_ctx);
@@ -121,6 +124,8 @@ extern "C" int msgl_prepare_decode(const int32_t* req_pool_indices, int32_t* seq
                  "msgl_prepare_decode: null pointer argument");
     MSGL_REQUIRE((next_tokens == nullptr) == (input_ids == nullptr), "msgl_prepare_decode: next_tokens and input_ids go together");
     MSGL_REQUIRE(r2t_stride >= max_ctx, "msgl_prepare_decode: r2t_stride %lld < max_ctx %d", (long long)r2t_stride, max_ctx);
+    MSGL_REQUIRE(req_to_page == nullptr || r2p_stride >= (max_ctx + page_size - 1) / page_size,
+                 "msgl_prepare_decode: r2p_stride %lld < pages of a row", (long long)r2p_stride);
     PrepParams p;
     p.req_idx = req_pool_indices;
     p.seq_lens = seq_lens;
@@ -130,6 +135,8 @@ extern "C" int msgl_prepare_decode(const int32_t* req_pool_indices, int32_t* seq
     p.free_range = free_range;
     p.r2t = req_to_token;
     p.r2t_stride = r2t_stride;
+    p.r2p = req_to_page;
+    p.r2p_stride = r2p_stride;
     p.max_ctx = max_ctx;
     p.positions = positions;
     p.out_loc = out_cache_loc;
@@ -140,4 +147,14 @@ extern "C" int msgl_prepare_decode(const int32_t* req_pool_indices, int32_t* seq
     p.ps = page_size;
     hipLaunchKernelGGL(decode_prepare_kernel, dim3(1), dim3(kPrepThreads), 0, static_cast<hipStream_t>(stream), p);
     return check_launch("decode_prepare_kernel");
+}
+
+extern "C" int msgl_prepare_decode(const int32_t* req_pool_indices, int32_t* seq_lens, int32_t* last_slots,
+                                   const int32_t* free_pages, int32_t free_capacity, int32_t* free_range, int32_t* req_to_token,
+                                   int64_t r2t_stride, int32_t max_ctx, int32_t* positions, int32_t* out_cache_loc,
+                                   const int32_t* next_tokens, int32_t* input_ids, int32_t* status, int bs, int page_size,
+                                   void* stream) {
+    return msgl_prepare_decode_paged(req_pool_indices, seq_lens, last_slots, free_pages, free_capacity, free_range, req_to_token,
+                                     r2t_stride, nullptr, 0, max_ctx, positions, out_cache_loc, next_tokens, input_ids, status, bs,
+                                     page_size, stream);
 }

@@ -49,5 +49,5 @@ extern "C" int msgl_get_variant(int which) {
     return msgl::variant(which);
 }
 
-extern "C" int msgl_abi_version(void) { return 16; }
+extern "C" int msgl_abi_version(void) { return 17; }
 extern "C" const char* msgl_last_error(void) { return msgl::g_err; }

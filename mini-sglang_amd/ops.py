@@ -586,7 +586,7 @@ def lm_head_argmax(hidden: torch.Tensor, weight: torch.Tensor, workspace: Option
 def prepare_decode(req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, last_slots: torch.Tensor, free_pages: torch.Tensor,
                    free_range: torch.Tensor, req_to_token: torch.Tensor, positions: torch.Tensor, out_cache_loc: torch.Tensor,
                    status: torch.Tensor, page_size: int, next_tokens: Optional[torch.Tensor] = None,
-                   input_ids: Optional[torch.Tensor] = None) -> None:
+                   input_ids: Optional[torch.Tensor] = None, req_to_page: Optional[torch.Tensor] = None) -> None:
     """One decode step's batch preparation on the device (see msgl_prepare_decode): advances ``seq_lens``,
     ``last_slots``, ``free_range[0]`` and writes ``positions``, ``out_cache_loc``, the page table and (optionally)
     ``input_ids`` in place.  ``status`` (int32[1]) becomes non-zero if the step was refused."""
@@ -603,9 +603,14 @@ def prepare_decode(req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, last_
         _dev_i32(next_tokens, "next_tokens")
         _dev_i32(input_ids, "input_ids")
         _need(next_tokens.numel() == bs and input_ids.numel() == bs, "next_tokens / input_ids: one entry per request")
-    _check(_lib.msgl_prepare_decode(
+    if req_to_page is not None:
+        _need(req_to_page.is_cuda and req_to_page.dtype == torch.int32 and req_to_page.dim() == 2 and req_to_page.stride(1) == 1
+              and req_to_page.shape[0] == req_to_token.shape[0], "req_to_page: int32 [rows, pages] on the GPU")
+    _check(_lib.msgl_prepare_decode_paged(
         req_pool_indices.data_ptr(), seq_lens.data_ptr(), last_slots.data_ptr(), free_pages.data_ptr(), free_pages.numel(),
-        free_range.data_ptr(), req_to_token.data_ptr(), req_to_token.stride(0), req_to_token.shape[1], positions.data_ptr(),
+        free_range.data_ptr(), req_to_token.data_ptr(), req_to_token.stride(0),
+        req_to_page.data_ptr() if req_to_page is not None else None, req_to_page.stride(0) if req_to_page is not None else 0,
+        req_to_token.shape[1], positions.data_ptr(),
         out_cache_loc.data_ptr(), next_tokens.data_ptr() if next_tokens is not None else None,
         input_ids.data_ptr() if input_ids is not None else None, status.data_ptr(), bs, page_size, _stream()))
 

@@ -160,7 +160,7 @@ class BatchInfo:
             r.last_slot = int(new_slots[pos + n - 1])
             pos += n
         dev = self.device
-        pool.req_to_token[(torch.cat(row_idx).to(dev), torch.cat(col_idx).to(dev))] = torch.cat(vals).to(dev)
+        pool.scatter_tokens(torch.cat(row_idx), torch.cat(col_idx), torch.cat(vals))
 
         self.input_ids = torch.tensor([t for r, p in zip(reqs, prefix_lens) for t in r.token_ids[p:]], dtype=torch.int32).to(dev)
         self.positions = torch.cat([torch.arange(p, s, dtype=torch.int32) for p, s in zip(prefix_lens, seq_lens)]).to(dev)
@@ -200,7 +200,7 @@ class BatchInfo:
             r.last_slot = s
         self.out_cache_loc = new_slots.to(dev)
         self.positions = old_lens.to(dev)
-        self.req_to_token_pool.req_to_token[(self.req_pool_indices.long(), self.positions.long())] = self.out_cache_loc
+        self.req_to_token_pool.scatter_tokens(torch.tensor([r.req_pool_idx for r in reqs], dtype=torch.int64), old_lens.long(), new_slots)
         self.input_ids = torch.tensor([r.last_token_id for r in reqs], dtype=torch.int32).to(dev)
 
     # ------------------------------------------------------------------ bookkeeping used by callers

@@ -45,7 +45,7 @@ def build_decode_state(cfg: Qwen3Config, bs: int, ctx: int, page_size: int, step
                                   max_ctx=cfg.max_position_embeddings)
     mr.page_allocator.free_page = torch.arange(ctx_pages + 1, pool_pages + 1, dtype=torch.int32)
     rows = mr.req_to_token_pool.alloc(bs)
-    mr.req_to_token_pool.req_to_token[torch.tensor(rows, device=device)] = pt.req_to_token.to(device)
+    mr.req_to_token_pool.load_rows(torch.tensor(rows, device=device), pt.req_to_token.to(device))
     for layer in range(cfg.num_hidden_layers):  # random K/V: a prefill would produce the same kind of tensor, slowly
         k, v = mr.kv_cache_pool.get_kv_buffer(layer)
         if kv_layout == "interleaved":

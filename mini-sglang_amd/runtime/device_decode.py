@@ -87,7 +87,8 @@ class DeviceDecodeLoop:
         mr = self.mr
         ops.prepare_decode(self.req_pool_indices, self.seq_lens, self.last_slots, self.free_pages, self.free_range,
                            mr.req_to_token_pool.req_to_token, self.positions, self.out_cache_loc, self.status, mr.page_size,
-                           next_tokens=self.next_tokens, input_ids=self.input_ids)
+                           next_tokens=self.next_tokens, input_ids=self.input_ids,
+                           req_to_page=mr.req_to_token_pool.req_to_page if mr.page_size > 1 else None)
         if hasattr(mr.attn_backend, "refresh_decode_plan"):  # launch order for the lengths this step attends over
             mr.attn_backend.refresh_decode_plan(self.bs, self.seq_lens)
         # greedy sampling on the vocabulary shard of each rank; the ranks exchange (value, index) pairs, not logits

@@ -162,7 +162,7 @@ def argmax_ref(logits: torch.Tensor) -> torch.Tensor:
 
 # --------------------------------------------------------------------------- fp64 ground truth (tests only)
 def prepare_decode_ref(req_pool_indices, seq_lens, last_slots, free_pages, free_head: int, req_to_token: torch.Tensor,
-                       page_size: int):
+                       page_size: int, req_to_page=None):
     """One decode step's batch preparation, request by request, as the reference does it
     (mini_sglang/managers/batch_info.py:247-302; page order: PageAllocator.alloc takes from the front of the
     free list, mini_sglang/mem_cache/token2kv.py:186-196).  Plain Python lists / ints in, written in place
@@ -176,6 +176,8 @@ def prepare_decode_ref(req_pool_indices, seq_lens, last_slots, free_pages, free_
     for i, old in enumerate(seq_lens):
         if ps == 1 or old % ps == 0:          # batch_info.py:277-283: a fresh page, first slot
             slot = int(free_pages[free_head]) * ps
+            if req_to_page is not None and ps > 1:    # the page half of the table (req2token.py:43-51): page id of the new page
+                req_to_page[int(req_pool_indices[i]), int(old) // ps] = int(free_pages[free_head])
             free_head += 1
         else:                                 # batch_info.py:286-291: the slot after the previous token's
             slot = int(last_slots[i]) + 1

@@ -108,4 +108,16 @@ def run_e2e(name, device, layers=None, backend_factory=None, new_tokens=None, us
         margins=torch.stack(margins), top1_logits=torch.stack(tops), logits_slices=torch.stack(slices), logits_wide=torch.stack(wide),
         out_cache_loc_first=locs[0], out_cache_loc_decode=torch.stack(locs[1:]),
         req_to_token_rows=torch.cat([r2t.req_to_token[r.req_pool_idx, : len(r.token_ids) - 1].cpu() for r in reqs]),
-        graph_steps=graph_steps)
+        graph_steps=graph_steps, req_to_page_matches_tokens=page_table_matches_tokens(r2t, reqs))
+
+
+def page_table_matches_tokens(pool, reqs) -> bool:
+    """The stored page table against the one derived from the token table, for every live token of every request."""
+    ps = pool.page_size
+    for r in reqs:
+        n = len(r.token_ids) - 1                       # the last sampled token has no slot yet
+        pages = -(-n // ps)
+        want = pool.req_to_token[r.req_pool_idx, : pages * ps: ps] // ps
+        if not torch.equal(pool.req_to_page[r.req_pool_idx, :pages], want):
+            return False
+    return True

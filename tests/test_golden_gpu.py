@@ -74,6 +74,7 @@ def _check_e2e(got, fx, need_identical_stream, wide_tol=2e-2):
     # integer outputs: slot assignment and page tables never depend on the sampled tokens
     for key in ("out_cache_loc_first", "out_cache_loc_decode", "req_to_token_rows"):
         assert torch.equal(got[key], fx[key]), key
+    assert got["req_to_page_matches_tokens"]
     same = (got["tokens"] == fx["tokens"])
     if need_identical_stream:
         assert bool(same.all()), f"greedy streams differ at {(~same).nonzero()[:4].tolist()}"
@@ -217,6 +218,9 @@ def test_device_chained_decode_equals_host_prepared_steps(ps, lens):
     for ra, rb in zip(batch_a.reqs, batch_b.reqs):
         n = len(ra.token_ids)
         assert torch.equal(mr_a.req_to_token_pool.req_to_token[ra.req_pool_idx, :n], mr_b.req_to_token_pool.req_to_token[rb.req_pool_idx, :n])
+    # the stored page table follows the token table on both sides (host scatters; the device kernel writes it itself)
+    assert gc.page_table_matches_tokens(mr_a.req_to_token_pool, batch_a.reqs)
+    assert gc.page_table_matches_tokens(mr_b.req_to_token_pool, batch_b.reqs)
     # and the two kinds of captured steps mixed on one backend: chained steps, then host-prepared graph replays
     mr_c, batch_c = build(use_graph=True)
     loop_c = DeviceDecodeLoop(mr_c, batch_c, max_steps=32)

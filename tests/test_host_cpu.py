@@ -209,3 +209,25 @@ def test_scalar_page_table_loads_of_the_matrix_core_decode_kernel_are_waited_for
                 hit = named & pending.keys()
                 assert not hit, f"{ins!r} names s{sorted(hit)[0]} between {pending[sorted(hit)[0]]!r} and its wait"
     assert checked >= 8, f"expected the kernel's scalar page-table loads in the code object, saw {checked}"
+
+
+def test_req_to_token_pool_keeps_a_page_table_that_matches_its_token_table():
+    """ReqToTokenPool.write_tokens (req2token.py:77-91) with a prefix of several pages, and the batch producers' scatter:
+    page i of a request is the page of its token i * page_size.  (The reference's writer strides its index vector by
+    page_size a second time and stores the ids of pages 0, page_size, 2 page_size, ... of the write instead.)"""
+    from mini_sglang_amd.mem_cache import ReqToTokenPool
+    ps = 4
+    pool = ReqToTokenPool(3, 64, ps, "cpu")
+    pages = torch.tensor([7, 2, 9, 5, 11], dtype=torch.int32)
+    slots = (pages[:, None] * ps + torch.arange(ps, dtype=torch.int32)[None, :]).reshape(-1)
+    pool.write_tokens(1, slice(0, 20), slots)
+    assert pool.req_to_page[1, :5].tolist() == [7, 2, 9, 5, 11]
+    assert torch.equal(pool.page_table(torch.tensor([1]), 5)[0], pool.req_to_page[1, :5])
+    with pytest.raises(AssertionError):
+        pool.write_tokens(1, slice(2, 8), slots[:6])
+    # scatter of scattered positions: two requests, one continuing inside a page, one starting a page
+    pool.scatter_tokens(torch.tensor([1, 2]), torch.tensor([20, 8]), torch.tensor([3 * ps, 6 * ps], dtype=torch.int32))
+    pool.scatter_tokens(torch.tensor([1, 2]), torch.tensor([21, 9]), torch.tensor([3 * ps + 1, 6 * ps + 1], dtype=torch.int32))
+    assert pool.req_to_page[1, 5] == 3 and pool.req_to_page[2, 2] == 6 and pool.req_to_token[1, 21] == 13
+    one = ReqToTokenPool(2, 8, 1, "cpu")
+    assert one.req_to_page is one.req_to_token

@@ -814,13 +814,19 @@ def test_prepare_decode_matches_oracle(bs, ps):
     toks = d(list(range(100, 100 + bs)))
     ids_d = torch.empty(bs, dtype=torch.int32, device=DEV)
     head = 7
+    # the page half of the table (one entry per page), kept by the kernel when the caller has one
+    r2p = torch.zeros((r2t.shape[0], -(-r2t.shape[1] // ps)), dtype=torch.int32) if ps > 1 else None
+    r2p_d = r2p.to(DEV) if r2p is not None else None
     for step in range(20):  # 20 steps: every request with page_size 16 crosses a page boundary at least once
-        positions, loc, head = orc.prepare_decode_ref(rows, lens, last, free_pages, head, r2t, ps)
-        ops.prepare_decode(rows_d, seq_d, last_d, free_d, head_d, r2t_d, pos_d, loc_d, status, ps, next_tokens=toks, input_ids=ids_d)
+        positions, loc, head = orc.prepare_decode_ref(rows, lens, last, free_pages, head, r2t, ps, req_to_page=r2p)
+        ops.prepare_decode(rows_d, seq_d, last_d, free_d, head_d, r2t_d, pos_d, loc_d, status, ps, next_tokens=toks, input_ids=ids_d,
+                           req_to_page=r2p_d)
         assert pos_d.tolist() == positions and loc_d.tolist() == loc, f"step {step}"
     assert status.item() == 0 and head_d.tolist() == [head, len(free_pages)]
     assert seq_d.tolist() == lens and last_d.tolist() == last
     assert torch.equal(r2t_d.cpu(), r2t)
+    if r2p is not None:
+        assert torch.equal(r2p_d.cpu(), r2p) and int((r2p != 0).sum()) > 0
     assert torch.equal(ids_d, toks)
 
 

@@ -59,6 +59,7 @@ def test_e2e_fixture_matches_oracle_harness(name):
     for key in ("tokens", "margins", "top1_logits", "logits_slices", "logits_wide", "out_cache_loc_first", "out_cache_loc_decode",
                 "req_to_token_rows"):
         assert torch.equal(got[key], fx[key]), key
+    assert got["req_to_page_matches_tokens"]
 
 
 def test_e2e_8b_layer_shapes_fixture_matches_oracle_harness():
