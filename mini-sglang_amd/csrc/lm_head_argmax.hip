@@ -252,6 +252,9 @@ extern "C" int msgl_lm_head_argmax(const void* x, int64_t x_stride, const void* 
     MSGL_REQUIRE(hidden >= 256 && hidden % 256 == 0, "msgl_lm_head_argmax: hidden %d must be a positive multiple of 256", hidden);
     MSGL_REQUIRE(x_stride >= hidden && w_stride >= hidden && x_stride % 8 == 0 && w_stride % 8 == 0 && aligned16(x) && aligned16(w),
                  "msgl_lm_head_argmax: rows must be 16-byte aligned and at least hidden elements apart");
+    // (the DMA loads address a lane's piece as a 32-bit byte offset from the tensor's base)
+    MSGL_REQUIRE((int64_t)bs * x_stride * 2 < (int64_t)1 << 32 && (int64_t)32 * w_stride * 2 < (int64_t)1 << 32,
+                 "msgl_lm_head_argmax: hidden states of %lld bytes or more are not supported", (long long)((int64_t)1 << 32));
     const size_t need = msgl_lm_head_argmax_workspace_bytes(bs, vocab);
     if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 3u)) {
         set_error("msgl_lm_head_argmax: workspace of %zu bytes, %zu needed (4-byte aligned)", workspace_bytes, need);

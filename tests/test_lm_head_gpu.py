@@ -109,3 +109,22 @@ def test_fused_head_full_vocabulary_successor_rows():
     ref = ops.argmax(torch.nn.functional.linear(x, w), return_values=True)
     assert torch.equal(ref[0], idx)
     assert bool(((val - ref[1]).abs() <= ref[1].abs() * 2 ** -7).all())
+
+
+def test_stream_read_yardstick_runs_in_every_form_and_refuses_bad_arguments():
+    """The benchmark's read-only yardstick (msgl_stream_read / _cfg / _span): every form reads a buffer without touching it
+    or the sink, and arguments outside the documented ranges are refused."""
+    ops = _ops()
+    buf = torch.randint(0, 2 ** 31 - 1, (1 << 20,), dtype=torch.int32, device=DEV)   # 4 MiB
+    keep = buf.clone()
+    sink = torch.zeros(64, dtype=torch.int32, device=DEV)
+    for unroll in (1, 2, 4, 8):
+        ops.stream_read(buf, sink, unroll, 16)
+        for span in (4, 64, 1024):
+            ops.stream_read(buf, sink, unroll, 8, span)
+    ops.stream_read(buf[: 1000 * 4 + 4], sink, 4, 8, 64)   # a length that is no multiple of a span or of a step
+    torch.cuda.synchronize()
+    assert torch.equal(buf, keep) and int(sink.abs().sum()) == 0
+    for bad in ((3, 16, 0), (4, 0, 0), (4, 65, 0), (4, 8, 6), (4, 8, 2)):
+        with pytest.raises(RuntimeError):
+            ops.stream_read(buf, sink, *bad)
