@@ -29,9 +29,10 @@ def timed(fn, n=20, warm=5):
 def main():
     dev = "cuda"
     torch.manual_seed(0)
-    for vocab, hidden in [(151936, 4096), (18992, 4096), (151936, 1024)]:
+    quick = os.environ.get("LH_QUICK") == "1"   # profiler passes: the full head at two batch sizes only
+    for vocab, hidden in ([(151936, 4096)] if quick else [(151936, 4096), (18992, 4096), (151936, 1024)]):
         w = (torch.randn(vocab, hidden, device=dev) * 0.02).to(torch.bfloat16)
-        for bs in (1, 16, 32, 64, 128, 256):
+        for bs in ((32, 64) if quick else (1, 16, 32, 64, 128, 256)):
             x = torch.randn(bs, hidden, device=dev).to(torch.bfloat16)
             ws = ops.lm_head_argmax_workspace(bs, vocab, dev)
             fused = timed(lambda: ops.lm_head_argmax(x, w, workspace=ws))
