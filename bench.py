@@ -242,7 +242,7 @@ def main():
             "launch_ms_stat": f"median of {args.steps} HIP-event intervals on the launch stream",
             "launch_ms_mean": round(dev_ms_mean, 4),
             "launch_ms_min_max": [round(per_step_ms[0], 4), round(per_step_ms[-1], 4)],
-            # the same two figures from the MEAN over the timed steps (what round 1 reported as achieved / frac)
+            # the same two figures from the MEAN over the timed steps (earlier records of this benchmark quoted the mean)
             "achieved_from_mean": round(bytes_per_step_rank / (dev_ms_mean * 1e-3) / 1e9, 1),
             "frac_from_mean": round(bytes_per_step_rank / (dev_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "bytes_per_launch": bytes_per_step_rank,
@@ -253,8 +253,8 @@ def main():
         result["distributed"] = dist_info
     # an on-box yardstick beside the spec peak: this library's read-only stream kernel (16 B per lane, non-temporal,
     # nothing stored) over the first layer's pool, which is far larger than the caches; its rate depends on the loads
-    # in flight per lane and the resident work groups, so the best of a small sweep is quoted (round 1 quoted a
-    # device-to-device copy here, round 2 the single configuration (8, 16))
+    # in flight per lane and the resident work groups, so the best of a small sweep is quoted (earlier records of this
+    # benchmark quoted a device-to-device copy here, then the single configuration (8, 16): see yardstick_changed_from)
     try:
         buf = pools[0][0] if args.layout == "split" else pools[0][0]._base
         buf = buf.view(-1)
@@ -424,7 +424,7 @@ def recorded_traffic(layout, bs, S, ps, Hq, Hkv):
 
 def recorded_extend_counters(prompt, prefix, ps, Hq, Hkv):
     """Matrix-core busy fraction of the extend launch from the committed profiler record (profiles/extend_counters.json,
-    written by scripts/profile_r02.sh), when it was taken on this shape; counters cannot be read inside a timed run."""
+    written by the profiler script under scripts/), when it was taken on this shape; counters cannot be read inside a timed run."""
     try:
         with open(os.path.join(ROOT, "profiles", "extend_counters.json")) as f:
             rec = json.load(f)
