@@ -747,11 +747,28 @@ def decode_e2e_small(args, barrier):
 
     try:
         bs, ctx, ps, samples, each = 64, 2048, 1, 6, 6
-        mr, batch = decode_loop.build_decode_state(Qwen3Config.qwen3_0_6b(), bs, ctx, ps, samples * each + 24, use_graph=not args.e2e_eager)
+        mr, batch = decode_loop.build_decode_state(Qwen3Config.qwen3_0_6b(), bs, ctx, ps, samples * each + 24 + 2 * (5 * 8 + 2), use_graph=not args.e2e_eager)
         sp = spread([dt / each * 1e3 for dt in decode_loop.time_decode_samples(mr, batch, samples, each, 4, barrier=barrier)], 3)
-        return {"model": "Qwen3-0.6B shape, random weights", "batch": bs, "ctx": ctx, "page_size": ps, "tp": 1,
+        info = {"model": "Qwen3-0.6B shape, random weights", "batch": bs, "ctx": ctx, "page_size": ps, "tp": 1,
                 "tok_per_s": round(bs / (sp["median"] * 1e-3), 1), "ms_per_step": sp["median"], "ms_per_step_spread": sp,
                 "steps": samples * each, "timing": f"median of {samples} samples of {each} steps", "hip_graph": not args.e2e_eager}
+        if not args.e2e_eager:
+            # the same steps chained on the device (step preparation, forward pass and greedy token in one graph, 8 steps
+            # per host synchronisation); at this batch size the head is the fused product + arg-max, timed beside
+            # the chain with GEMM + argmax instead
+            try:
+                for key, fused in (("chained", True), ("chained_gemm_argmax", False)):
+                    mr.fused_head = fused
+                    dts = decode_loop.time_decode_chained_samples(mr, batch, 5, 8, 2, barrier=barrier)
+                    spc = spread([dt / 8 * 1e3 for dt in dts], 3)
+                    info.update({f"tok_per_s_{key}": round(bs / (spc["median"] * 1e-3), 1), f"ms_per_step_{key}": spc["median"],
+                                 f"ms_per_step_{key}_spread": spc})
+                info["chain"] = 8
+            except Exception as e:  # noqa: BLE001
+                info["chained_error"] = f"{type(e).__name__}: {e}"[:200]
+            finally:
+                mr.fused_head = True
+        return info
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
