@@ -91,13 +91,52 @@ __host__ __device__ __forceinline__ constexpr int pack_slice(int e, int s, int p
     return ready > last_reader + 4 ? ready : last_reader + 4;
 }
 
+// Staging of a 64-key tile by the 256 threads of the four-wave kernel: a thread owns CPT 16-byte chunks (16 / CPT
+// chunks apart) of 4 / CPT keys, four units of work either way (unit u = key index * CPT + chunk index).  The more
+// chunks of one key a thread owns, the less address work per tile: with CPT = 4 it is ONE page-table entry and ONE row
+// address per thread and tile, the other three chunks are that address plus 64, 128 and 192 bytes (a quad of lanes reads
+// 64 contiguous bytes of a K or V row and writes 64 contiguous bytes of its LDS image).  Measured on 16k-token prompts,
+// cycles per steady-state iteration / TFLOP/s: CPT = 1 (four keys, four addresses) 3325 / 1061, CPT = 2 3271 / 1071,
+// CPT = 4 3219 / 1095.
+#ifndef EXT_CPT
+#define EXT_CPT 4
+#endif
+template <int CPT>
+struct WideStage {
+    static constexpr int KPT = 4 / CPT;          // keys per thread and tile
+    static constexpr int KSTEP = 16 * CPT;       // distance between a thread's keys
+    static constexpr int LANES = 16 / CPT;       // threads per key row
+    u32x4_t k[4], v[4];
+    uint32_t slot[KPT];
+    __device__ __forceinline__ static int chunk0(int tid) { return tid & (LANES - 1); }
+    __device__ __forceinline__ static int skey(int tid) { return tid / LANES; }
+    __device__ __forceinline__ void lookup(const int32_t* r2t_row, int kt, int sk, int kv_len) {
+        const int base = kt * kBN + sk;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) slot[i] = (uint32_t)r2t_row[min(base + i * KSTEP, kv_len - 1)];
+    }
+    // kcol / vcol: the thread's first chunk of slot 0's row
+    __device__ __forceinline__ void load_unit(const uint16_t* kcol, const uint16_t* vcol, uint32_t cache_stride, int u) {
+        const int i = u / CPT, j = u % CPT;
+        const uint64_t o = (uint64_t)slot[i] * cache_stride + j * (LANES * 8);
+        k[u] = *reinterpret_cast<const u32x4_t*>(kcol + o);
+        v[u] = *reinterpret_cast<const u32x4_t*>(vcol + o);
+    }
+    template <int KROW>
+    __device__ __forceinline__ void write_unit(char* tile, int sk, int c0, int u) const {
+        const int i = u / CPT, j = u % CPT;
+        const int key = sk + i * KSTEP, chunk = c0 + j * LANES;
+        *reinterpret_cast<u32x4_t*>(tile + key * KROW + (chunk << 4)) = k[u];
+        *reinterpret_cast<u32x4_t*>(tile + kBN * KROW + key * kVRow + (chunk << 4)) = v[u];
+    }
+};
+
 __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams p) {
 #ifndef EXT_KD
 #define EXT_KD 2
 #endif
     constexpr int KD = EXT_KD;  // K fragments are requested this many k-steps (of two slices) ahead of their use
-    constexpr int KPT = 4;     // keys staged per thread and tile
-    constexpr int KSTEP = 16;  // distance between a thread's staged keys
+    using Stage = WideStage<EXT_CPT>;
     // a ring slot: 64 K rows padded to kKRowPadded bytes (the chunks of a row in place: a lane's K fragments of the eight
     // k-steps are one address plus immediates), then 64 V rows of kVRow bytes
     constexpr int KROW = kKRowPadded, kKImage = kBN * KROW, kSlot = kKImage + kBN * kVRow;
@@ -276,8 +315,8 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
         l[e] = l[e] * alpha_pend[e] + sum_tile(e);
     };
 
-    const int c16 = tid & 15;
-    const int skey = tid >> 4;
+    const int c16 = Stage::chunk0(tid);
+    const int skey = Stage::skey(tid);
     const uint16_t* kcol = p.kc + hk * kHD + c16 * 8;
     const uint16_t* vcol = p.vc + hk * kHD + c16 * 8;
     // The ring has four slots: in the steady state an iteration reads three tiles (V of tile t, the second half of K of
@@ -288,15 +327,24 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
         const int c = s0;
         s0 = s1, s1 = s2, s2 = s3, s3 = c;
     };
-    StageSlots<KPT> slots = stage_slots<KPT, KSTEP>(r2t_row, 0, skey, kv_len);
-    StageRegs<KPT> stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
+    Stage stg;
+    auto load_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) stg.load_unit(kcol, vcol, p.cache_stride, u);
+    };
+    auto write_tile = [&](char* tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) stg.template write_unit<KROW>(tile, skey, c16, u);
+    };
+    stg.lookup(r2t_row, 0, skey, kv_len);
+    load_tile();
 #pragma unroll
     for (int k = 1; k <= 3; ++k) {
-        slots = stage_slots<KPT, KSTEP>(r2t_row, min(k, nkt - 1), skey, kv_len);
-        stage_write<KPT, KSTEP, KROW>(lds + (k - 1) * kSlot, skey, c16, stg);
-        stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);
+        stg.lookup(r2t_row, min(k, nkt - 1), skey, kv_len);
+        write_tile(lds + (k - 1) * kSlot);
+        load_tile();
     }
-    slots = stage_slots<KPT, KSTEP>(r2t_row, min(4, nkt - 1), skey, kv_len);
+    stg.lookup(r2t_row, min(4, nkt - 1), skey, kv_len);
     __syncthreads();
     if (my_nkt > 0) {
         f32x16_t s[2][2];
@@ -388,9 +436,9 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
             if constexpr (g >= 48 - 2 * KD && g <= 62 - 2 * KD && (g & 1) == 0 && !(kKo & 64))
                 ka[((g - (48 - 2 * KD)) >> 1) % (KD + 1)] = k_frag(kp2, (g - (48 - 2 * KD)) >> 1);
             // ---- ring: tile t+3 into the free slot, tile t+4 into the registers that frees, then the slots of tile t+5
-            if constexpr (g < 32 && (g & 7) == 1 && !(kKo & 16)) stage_write_one<KSTEP, KROW>(lds + s3, skey, c16, stg, g >> 3);
-            if constexpr (g < 32 && (g & 7) == 5 && !(kKo & 32)) stage_load_one(kcol, vcol, p.cache_stride, slots, stg, g >> 3);
-            if constexpr (g == 33) slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + 5, nkt - 1), skey, kv_len);
+            if constexpr (g < 32 && (g & 7) == 1 && !(kKo & 16)) stg.template write_unit<KROW>(lds + s3, skey, c16, g >> 3);
+            if constexpr (g < 32 && (g & 7) == 5 && !(kKo & 32)) stg.load_unit(kcol, vcol, p.cache_stride, g >> 3);
+            if constexpr (g == 33) stg.lookup(r2t_row, min(t + 5, nkt - 1), skey, kv_len);
             // ---- the slice's matrix instruction
             if constexpr (blk == 0 || blk == 2) {
                 constexpr int ks = (blk ? 2 : 0) + (j >> 3), d = (j & 7) >> 1, e = j & 1;
@@ -457,6 +505,8 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
                       "schedule");
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
+            // (plain C++ adds: the compiler pairs the two heads' into v_pk_add_f32 and sees the v_exp_f32 in front of them;
+            // single v_add_f32 statements here measured 2 % slower on long prompts)
             ts[e][1] += sb[e][15];
             pf[e][3].w = pack_bf16(sb[e][14], sb[e][15]);
             l_before[e] = l[e];
@@ -504,9 +554,9 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
     // ---- the diagonal tiles, then the tiles only other waves of the work group still need ----
     for (; t < nkt; ++t) {
         __syncthreads();
-        stage_write<KPT, KSTEP, KROW>(lds + s3, skey, c16, stg);
-        stg = stage_load<KPT>(kcol, vcol, p.cache_stride, slots);  // past the last tile: a copy of it into a free slot
-        slots = stage_slots<KPT, KSTEP>(r2t_row, min(t + 5, nkt - 1), skey, kv_len);
+        write_tile(lds + s3);
+        load_tile();  // past the last tile: a copy of it into a free slot
+        stg.lookup(r2t_row, min(t + 5, nkt - 1), skey, kv_len);
         if (t < my_nkt) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
