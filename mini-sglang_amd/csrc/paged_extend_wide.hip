@@ -133,7 +133,7 @@ struct WideStage {
 
 __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams p) {
 #ifndef EXT_KD
-#define EXT_KD 2
+#define EXT_KD 3
 #endif
     constexpr int KD = EXT_KD;  // K fragments are requested this many k-steps (of two slices) ahead of their use
     using Stage = WideStage<EXT_CPT>;
