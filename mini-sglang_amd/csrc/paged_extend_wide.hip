@@ -60,6 +60,19 @@ __device__ __forceinline__ float add_alone(float a, float b) {
 #define EXT_KO 0
 #endif
 constexpr int kKo = EXT_KO;
+// Where in the 64 slices of an iteration the ring operations sit: unit u's LDS write in slice kRingOff + 8 u + kRingWrite, its
+// reload in slice kRingOff + 8 u + kRingLoad, the next page-table lookup in slice kRingOff + 33.
+#ifndef EXT_RING_OFF
+#define EXT_RING_OFF 0
+#endif
+#ifndef EXT_RING_WRITE
+#define EXT_RING_WRITE 1
+#endif
+#ifndef EXT_RING_LOAD
+#define EXT_RING_LOAD 5
+#endif
+constexpr int kRingOff = EXT_RING_OFF, kRingWrite = EXT_RING_WRITE, kRingLoad = EXT_RING_LOAD;
+static_assert(kRingOff % 8 == 0 && kRingOff + 33 < 64 && kRingWrite < kRingLoad && kRingLoad < 8, "ring schedule");
 
 // f(integral_constant<int, Lo>), ..., f(integral_constant<int, Hi - 1>): a loop whose index is a constant expression in
 // the body, so that register arrays are indexed by constants before any optimisation runs
@@ -436,9 +449,11 @@ __global__ __launch_bounds__(256, 1) void paged_extend_wide_kernel(ExtendParams 
             if constexpr (g >= 48 - 2 * KD && g <= 62 - 2 * KD && (g & 1) == 0 && !(kKo & 64))
                 ka[((g - (48 - 2 * KD)) >> 1) % (KD + 1)] = k_frag(kp2, (g - (48 - 2 * KD)) >> 1);
             // ---- ring: tile t+3 into the free slot, tile t+4 into the registers that frees, then the slots of tile t+5
-            if constexpr (g < 32 && (g & 7) == 1 && !(kKo & 16)) stg.template write_unit<KROW>(lds + s3, skey, c16, g >> 3);
-            if constexpr (g < 32 && (g & 7) == 5 && !(kKo & 32)) stg.load_unit(kcol, vcol, p.cache_stride, g >> 3);
-            if constexpr (g == 33) stg.lookup(r2t_row, min(t + 5, nkt - 1), skey, kv_len);
+            if constexpr (g >= kRingOff && g < kRingOff + 32 && (g & 7) == kRingWrite && !(kKo & 16))
+                stg.template write_unit<KROW>(lds + s3, skey, c16, (g - kRingOff) >> 3);
+            if constexpr (g >= kRingOff && g < kRingOff + 32 && (g & 7) == kRingLoad && !(kKo & 32))
+                stg.load_unit(kcol, vcol, p.cache_stride, (g - kRingOff) >> 3);
+            if constexpr (g == kRingOff + 33) stg.lookup(r2t_row, min(t + 5, nkt - 1), skey, kv_len);
             // ---- the slice's matrix instruction
             if constexpr (blk == 0 || blk == 2) {
                 constexpr int ks = (blk ? 2 : 0) + (j >> 3), d = (j & 7) >> 1, e = j & 1;
