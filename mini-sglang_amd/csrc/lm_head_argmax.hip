@@ -72,27 +72,32 @@ __device__ __forceinline__ void lh_wait_loads() {  // at most N of the wave's lo
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Work group = 4 waves = 128 weight rows x 32 NB batch columns, k in chunks of 128 elements (256 bytes of a row).
-// Everything reaches LDS by DMA in whole 256-byte row pieces (16 lanes a row, 4 rows an instruction: coalesced, which a
-// load straight into the matrix instruction's operand layout - neighbouring lanes on neighbouring rows - is not):
-//   weights   wave-private ring of D slots of 32 rows (8 KiB), read once, non-temporal;
+// Work group = 4 waves = 128 weight rows x 32 NB batch columns, k in chunks of CK elements (a 256- or 512-byte piece of
+// a row).  Everything reaches LDS by DMA in whole row pieces (16 or 32 lanes a row, 4 or 2 rows an instruction:
+// coalesced, which a load straight into the matrix instruction's operand layout - neighbouring lanes on neighbouring
+// rows - is not; the longer piece also opens half as many DRAM pages per byte):
+//   weights   wave-private ring of D slots of 32 row pieces, read once, non-temporal;
 //   X^T       one image of 32 NB columns per slot, shared by the four waves, each bringing a quarter of it (from L2).
 // A 16-byte piece q of row r sits at position q ^ (r & 15) of its row (the swizzle is applied to the source address):
 // the ds_read_b128 fragment reads of 16 different rows then fall on 16 different bank groups.
 // Iteration c: wait for chunk c's own loads, barrier (X^T of chunk c complete, everyone done with chunk c - 1), issue
 // chunk c + D - 1 into the slot that frees, multiply chunk c.  D - 1 chunks per wave are in flight while it multiplies.
-template <int NB, int D>
+template <int NB, int D, int CK>
 __global__ __launch_bounds__(256, 1) void lm_head_argmax_kernel(LmHeadParams p) {
+    static_assert(CK == 128 || CK == 256, "a row piece is 256 or 512 bytes");
     constexpr int COLS = 32 * NB;
-    constexpr int CK = 128;
-    constexpr int kXImage = COLS * 256, kWImage = 32 * 256, kSlot = kXImage + 4 * kWImage;
-    constexpr int NXI = COLS / 16;          // X^T load instructions per wave and chunk (4 columns each)
-    constexpr int PER_CHUNK = 8 + NXI;      // loads a wave issues per chunk
+    constexpr int RB = CK * 2;                 // bytes of a row piece
+    constexpr int LPR = RB / 16;               // lanes that bring one row piece
+    constexpr int RPI = 64 / LPR;              // rows per load instruction
+    constexpr int NWI = 32 / RPI;              // weight load instructions per wave and chunk
+    constexpr int kXImage = COLS * RB, kWImage = 32 * RB, kSlot = kXImage + 4 * kWImage;
+    constexpr int NXI = COLS / 4 / RPI;        // X^T load instructions per wave and chunk (a quarter of the columns)
+    constexpr int PER_CHUNK = NWI + NXI;       // loads a wave issues per chunk
     extern __shared__ __attribute__((aligned(1024))) char lds[];  // D * kSlot; the epilogue reuses the start
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
-    const int g4 = lane >> 4, q = lane & 15;
+    const int gr = lane / LPR, q = lane % LPR;   // row within a load instruction, 16-byte piece within the row
     const int row0 = blockIdx.x * kLhRows + wave * 32;
     const int col0 = blockIdx.y * COLS;
     const int nchunks = p.hidden / CK;
@@ -101,20 +106,20 @@ __global__ __launch_bounds__(256, 1) void lm_head_argmax_kernel(LmHeadParams p) 
     // sources: rows past the vocabulary and columns past the batch re-read the last valid one (left out in the epilogue)
     const int base_row = min(row0, p.vocab - 1);
     const uint16_t* wbase = p.w + (int64_t)base_row * p.w_stride;
-    uint32_t woff[8], xoff[NXI];
+    uint32_t woff[NWI], xoff[NXI];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = 4 * i + g4;
+    for (int i = 0; i < NWI; ++i) {
+        const int r = RPI * i + gr;
         woff[i] = (uint32_t)((min(row0 + r, p.vocab - 1) - base_row) * p.w_stride * 2 + ((q ^ (r & 15)) << 4));
     }
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
-        const int r = wave * (COLS / 4) + 4 * i + g4;  // column of the image
+        const int r = wave * (COLS / 4) + RPI * i + gr;  // column of the image
         xoff[i] = (uint32_t)(min(col0 + r, p.bs - 1) * p.x_stride * 2 + ((q ^ (r & 15)) << 4));
     }
     auto issue_chunk = [&](int c, int slot) __attribute__((always_inline)) {
         c = min(c, nchunks - 1);  // (past the end: a re-read of the last chunk that nothing consumes)
-        const uint32_t xdst = lds0 + slot * kSlot + wave * (COLS / 4) * 256;
+        const uint32_t xdst = lds0 + slot * kSlot + wave * (COLS / 4) * RB;
         const uint32_t wdst = lds0 + slot * kSlot + kXImage + wave * kWImage;
         const uint16_t* xb = p.x + c * CK;
         const uint16_t* wb = wbase + c * CK;
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(256, 1) void lm_head_argmax_kernel(LmHeadParams p) 
 #pragma unroll
         for (int i = 0; i < NXI; ++i) lh_dma_1k<false>(xb, xoff[i], xdst + i * 1024);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) lh_dma_1k<true>(wb, woff[i], wdst + i * 1024);
+        for (int i = 0; i < NWI; ++i) lh_dma_1k<true>(wb, woff[i], wdst + i * 1024);
     };
 
     lf32x16_t acc[NB];
@@ -131,10 +136,10 @@ __global__ __launch_bounds__(256, 1) void lm_head_argmax_kernel(LmHeadParams p) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 
-    // fragment reads: row n of an image, pieces 2 j + h
-    int fpos[8];
+    // fragment reads: row n of an image, pieces 2 j + h (the low four bits of a piece's position are swizzled by the row)
+    int fpos[CK / 16];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) fpos[j] = n * 256 + (((2 * j + h) ^ (n & 15)) << 4);
+    for (int j = 0; j < CK / 16; ++j) fpos[j] = n * RB + (((2 * j + h) ^ (n & 15)) << 4);
 
 #pragma unroll
     for (int s = 0; s < D - 1; ++s) issue_chunk(s, s);
@@ -146,11 +151,11 @@ __global__ __launch_bounds__(256, 1) void lm_head_argmax_kernel(LmHeadParams p) 
         const char* ximg = lds + slot * kSlot;
         const char* wimg = ximg + kXImage + wave * kWImage;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < CK / 16; ++j) {
             const lhu32x4_t a = *reinterpret_cast<const lhu32x4_t*>(wimg + fpos[j]);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const lhu32x4_t bf = *reinterpret_cast<const lhu32x4_t*>(ximg + b * 32 * 256 + fpos[j]);
+                const lhu32x4_t bf = *reinterpret_cast<const lhu32x4_t*>(ximg + b * 32 * RB + fpos[j]);
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(lbf16x8_t, a), __builtin_bit_cast(lbf16x8_t, bf), acc[b], 0, 0, 0);
             }
         }
@@ -221,19 +226,20 @@ __global__ __launch_bounds__(256) void lm_head_argmax_finish_kernel(const float*
     }
 }
 
-template <int NB, int D>
+template <int NB, int D, int CK>
 static int launch_lm_head(const LmHeadParams& p, int tiles, hipStream_t st) {
-    constexpr int kLds = D * (32 * NB * 256 + 4 * 32 * 256);
+    constexpr int kLds = D * (32 * NB * CK * 2 + 4 * 32 * CK * 2);
+    static_assert(kLds <= 160 * 1024, "LDS of a compute unit");
     static PerDeviceOnce once;
     if (!once.ensure([] {
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(lm_head_argmax_kernel<NB, D>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kLds) == hipSuccess;
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(lm_head_argmax_kernel<NB, D, CK>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
         })) {
         set_error("msgl_lm_head_argmax: cannot reserve %d bytes of LDS", kLds);
         return MSGL_E_LAUNCH;
     }
     const dim3 grid((unsigned)tiles, (unsigned)((p.bs + 32 * NB - 1) / (32 * NB)));
-    hipLaunchKernelGGL((lm_head_argmax_kernel<NB, D>), grid, dim3(256), kLds, st, p);
+    hipLaunchKernelGGL((lm_head_argmax_kernel<NB, D, CK>), grid, dim3(256), kLds, st, p);
     return check_launch("lm_head_argmax_kernel");
 }
 
@@ -273,9 +279,13 @@ extern "C" int msgl_lm_head_argmax(const void* x, int64_t x_stride, const void* 
     p.hidden = hidden;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc;
-    if (bs <= 32) rc = launch_lm_head<1, 3>(p, tiles, st);
-    else if (bs <= 64) rc = launch_lm_head<2, 3>(p, tiles, st);
-    else rc = launch_lm_head<4, 2>(p, tiles, st);
+    // (up to 32 columns the LDS holds two slots of 512-byte row pieces: 5.26 against 4.8 TB/s with three slots of 256-byte
+    // ones on a 151 936 x 4096 head; short rows and launches of less than two row blocks per compute unit are ahead with
+    // the shorter pieces, whose pipeline fills sooner)
+    if (bs <= 32 && hidden >= 2048 && tiles >= 2 * device_cus()) rc = launch_lm_head<1, 2, 256>(p, tiles, st);
+    else if (bs <= 32) rc = launch_lm_head<1, 3, 128>(p, tiles, st);
+    else if (bs <= 64) rc = launch_lm_head<2, 3, 128>(p, tiles, st);
+    else rc = launch_lm_head<4, 2, 128>(p, tiles, st);
     if (rc != MSGL_OK) return rc;
     hipLaunchKernelGGL(lm_head_argmax_finish_kernel, dim3((unsigned)bs), dim3(256), 0, st, p.ws_val, p.ws_idx, tiles, bs, out, out_val);
     return check_launch("lm_head_argmax_finish_kernel");
