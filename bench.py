@@ -707,7 +707,7 @@ def layer_kernels(args, world, rank):
         # unfused pair it replaces (library GEMM writing [bs, vocab / tp] logits, then msgl_argmax_val)
         vocab = 151936 // world
         head = (torch.randn(vocab, hid, device=dev) * 0.02).bfloat16()
-        for bs in (64, 128):
+        for bs in (32, 64, 128):
             hx = torch.randn(bs, hid, device=dev).bfloat16()
             hws = ops.lm_head_argmax_workspace(bs, vocab, dev)
             record("lm_head_argmax", bs, vocab * hid * 2 + bs * hid * 2, lambda i: ops.lm_head_argmax(hx, head, workspace=hws), 4)
