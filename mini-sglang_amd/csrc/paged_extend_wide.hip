@@ -61,9 +61,11 @@ __device__ __forceinline__ float add_alone(float a, float b) {
 #endif
 constexpr int kKo = EXT_KO;
 // Where in the 64 slices of an iteration the ring operations sit: unit u's LDS write in slice kRingOff + 8 u + kRingWrite, its
-// reload in slice kRingOff + 8 u + kRingLoad, the next page-table lookup in slice kRingOff + 33.
+// reload in slice kRingOff + 8 u + kRingLoad, the next page-table lookup in slice kRingOff + 33.  Measured on 16k prompts
+// (offset, write, load): (0, 1, 5) 3145 cycles / 1108 TFLOP/s, (8, 1, 5) 3195 / 1101, (24, 1, 5) 3070 / 1121,
+// (24, 3, 7) 3078 / 1120, (24, 2, 6) 3181 / 1103, (0, 0, 4) 3288 / 1124 of 1148.
 #ifndef EXT_RING_OFF
-#define EXT_RING_OFF 0
+#define EXT_RING_OFF 24
 #endif
 #ifndef EXT_RING_WRITE
 #define EXT_RING_WRITE 1
