@@ -128,3 +128,29 @@ def test_stream_read_yardstick_runs_in_every_form_and_refuses_bad_arguments():
     for bad in ((3, 16, 0), (4, 0, 0), (4, 65, 0), (4, 8, 6), (4, 8, 2)):
         with pytest.raises(RuntimeError):
             ops.stream_read(buf, sink, *bad)
+
+
+def test_fused_head_seeded_random_shapes():
+    """Forty seeded shapes (batch 1-200, 1-6000 rows, rows of 256-2048 elements, input scales over two decades): the same
+    decidability rule as above on every one of them."""
+    import random
+    ops = _ops()
+    rng = random.Random(20260)
+    for case in range(40):
+        bs = rng.choice([1, 2, 7, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 200])
+        vocab = rng.choice([1, 5, 31, 32, 33, 127, 128, 129, 1000, 2049, 6000])
+        hidden = rng.choice([256, 512, 768, 1024, 2048])
+        x, w = _inputs(bs, vocab, hidden, 5000 + case, scale=rng.choice([0.1, 1.0, 10.0]))
+        exact, _, want = _oracle(x, w)
+        idx, val = ops.lm_head_argmax(x.to(DEV), w.to(DEV))
+        idx, val = idx.cpu().long(), val.cpu()
+        assert int(idx.min()) >= 0 and int(idx.max()) < vocab, (case, bs, vocab, hidden)
+        best = exact.max(dim=-1).values
+        ulp = torch.exp2(torch.floor(torch.log2(best.abs().clamp_min(1e-30))) - 7)
+        chosen = exact.gather(1, idx.view(-1, 1))[:, 0]
+        assert bool((chosen >= best - ulp).all()), (case, bs, vocab, hidden)
+        assert bool(((val.double() - chosen).abs() <= ulp).all()), (case, bs, vocab, hidden)
+        if vocab > 1:
+            top2 = exact.topk(2, dim=-1).values
+            clear = (top2[:, 0] - top2[:, 1]) > 2 * ulp
+            assert bool((idx[clear] == want[clear]).all()), (case, bs, vocab, hidden)
